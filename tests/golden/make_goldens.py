@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Run only in the build container (the reference lives at /root/reference and
+never travels to the GPU box):
+
+    PYTHONHASHSEED=0 PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+PYTHONHASHSEED=0 matters: `_handle_pit_stops` calls `set.pop()` on a
+two-string set (reference src/simulation.py:486,488), whose result depends on
+the string hash seed.  The outcomes observed under hashseed 0
+are recorded in cases.json["set_pop"] and fed to the oracle / the HIP path as
+an explicit rule.
+
+What is written (all data, no reference source text):
+  cases.json            inputs of every case (config, per-driver dicts,
+                        grid_probs) exactly as they were handed to
+                        RaceSimulator.run_monte_carlo, plus meta
+  <case>.npz            hist   [n, n] int64   counts[driver][position-1]
+                        orders [m, n] uint8   driver index at finishing pos p
+                        grids  [m, n] uint8   driver index on grid slot p
+                        trace_* per-lap state of the first T sims (after every
+                        _update_positions call), cars in driver-index order
+  mt_streams.npz        G4: raw draws of the two Mersenne-Twister streams
+  sample_grid.npz       G5: _sample_grid outputs
+  misc.json             G6: _predict_quali matrix inputs/outputs,
+                        _create_race_config fields, brier_score values
+  ref_stat_<case>.npz   big-N reference histograms (several seeds) for the
+                        statistical link HIP-Philox ~ reference-MT
+"""
+import json
+import os
+import random
+import sys
+import time
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+# predictor.py / validation.py import fastf1 at module scope only for the
+# data loader; an inert module object is enough to import them.
+sys.modules.setdefault('fastf1', types.ModuleType('fastf1'))
+
+from src.simulation import RaceSimulator, RaceConfig  # noqa: E402
+from src.config import DRIVER_TEAMS, TIRE_COMPOUNDS, DEFAULT_DNF_RATES, CIRCUITS  # noqa: E402
+from src.predictor import F1Predictor  # noqa: E402
+from src.elo import F1EloSystem  # noqa: E402
+from src.validation import brier_score, podium_accuracy  # noqa: E402
+
+COMPOUND_ID = {'SOFT': 0, 'MEDIUM': 1, 'HARD': 2, 'INTERMEDIATE': 3, 'WET': 4}
+
+
+def make_predictor(ratings):
+    p = F1Predictor.__new__(F1Predictor)
+    p.elo_system = F1EloSystem()
+    p.elo_system.ratings = {d: {'quali': r, 'race': r} for d, r in ratings.items()}
+    return p
+
+
+def elo_grid(drivers):
+    """quali = race = 1700 - 20 i, empty feature dicts."""
+    p = make_predictor({d: 1700.0 - 20.0 * i for i, d in enumerate(drivers)})
+    g = p._predict_quali(drivers, {})
+    return {d: [float(x) for x in g[d]] for d in drivers}
+
+
+def config_dict(laps, pit_loss, overtake_delta, sc=0.01, vsc=0.015, red=0.002,
+                tire_compounds=None, dnf_rates=None, driver_teams=None, drs_delta=0.3,
+                drs_zones=2, dirty_thr=2.0, dirty_pen=0.5):
+    return dict(
+        total_laps=laps, pit_loss=pit_loss, overtake_delta=overtake_delta,
+        sc_probability=sc, vsc_probability=vsc, red_flag_probability=red,
+        dnf_rates=dict(dnf_rates if dnf_rates is not None else DEFAULT_DNF_RATES),
+        drs_zones=drs_zones, drs_delta=drs_delta,
+        tire_compounds={k: dict(v) for k, v in (tire_compounds or TIRE_COMPOUNDS).items()},
+        driver_teams=dict(driver_teams if driver_teams is not None else DRIVER_TEAMS),
+        dirty_air_threshold=dirty_thr, dirty_air_penalty=dirty_pen,
+    )
+
+
+def canonical_case(name, laps, circuit, n_sims, n_trace, seed=42):
+    drivers = list(DRIVER_TEAMS.keys())
+    c = CIRCUITS[circuit]
+    return dict(
+        name=name, n_sims=n_sims, n_orders=min(n_sims, 256), n_trace=n_trace, seed=seed,
+        track_condition='dry',
+        config=config_dict(laps, c['pit_loss'], c['overtake_delta'], drs_zones=c['drs_zones']),
+        grid_probs=elo_grid(drivers),
+        base_pace={d: 90.0 + 0.1 * i for i, d in enumerate(drivers)},
+        tire_deg={d: 0.05 for d in drivers},
+        driver_variance={d: 0.15 * 1.2 for d in drivers},
+        driver_dnf_rates={d: 0.05 / laps for d in drivers},
+    )
+
+
+def build_cases():
+    cases = []
+    # S60 / S78: the two bench configurations of SURVEY.md 8(d).
+    cases.append(canonical_case('S60', 60, 'Bahrain', 2000, 24))
+    cases.append(canonical_case('S78', 78, 'Monaco', 2000, 16))
+    # S50: Q13-sensitive race length (MEDIUM starters first pit with 20 < remaining <= 30).
+    cases.append(canonical_case('S50', 50, 'Saudi Arabia', 2000, 24))
+
+    # EVT: event storm (SC / VSC / red flag on most laps), short race, strong DNF rates
+    # so that lap-1 double retirements (Q17) and empty-field corner cases show up.
+    drivers = list(DRIVER_TEAMS.keys())
+    evt = canonical_case('EVT', 34, 'Italy', 1500, 48, seed=7)
+    evt['config'].update(sc_probability=0.12, vsc_probability=0.15, red_flag_probability=0.06)
+    evt['config']['dnf_rates'] = {t: r * 12 for t, r in DEFAULT_DNF_RATES.items()}
+    evt['driver_dnf_rates'] = None  # team rates on every lap (reference :190-193)
+    evt['driver_variance'] = {d: 0.15 for d in drivers}
+    cases.append(evt)
+
+    # HET: heterogeneous per-driver inputs, a 21-car field with an unknown driver,
+    # missing dict entries (exercises every .get default of the reference),
+    # high / low degradation branches of the pit logic (Q12), dynamic compound table,
+    # one-hot actual grid with penalties piled on the last slot (Q18).
+    rng = random.Random(1234)
+    drv = list(DRIVER_TEAMS.keys()) + ['XXX']
+    n = len(drv)
+    p = make_predictor({})
+    onehot = {}
+    order = drv[:]
+    rng.shuffle(order)
+    for slot, d in enumerate(order):
+        v = [0.0] * n
+        v[slot] = 1.0
+        onehot[d] = v
+    onehot = {d: onehot[d] for d in drv}
+    onehot = p._adjust_for_penalties(onehot, {order[2]: 'engine', order[5]: 'full_pu',
+                                              order[9]: 5, order[11]: 'pitlane_start', order[15]: 10})
+    onehot = {d: [float(x) for x in onehot[d]] for d in drv}
+    tc = {k: dict(v) for k, v in TIRE_COMPOUNDS.items()}
+    tc['SOFT']['pace_delta'] = -0.63
+    tc['HARD']['pace_delta'] = 0.41
+    het = dict(
+        name='HET', n_sims=1500, n_orders=256, n_trace=24, seed=2024, track_condition='dry',
+        config=config_dict(57, 21.0, 0.6, tire_compounds=tc),
+        grid_probs=onehot,
+        base_pace={d: 88.0 + 2.5 * rng.random() for d in drv if d not in ('HUL',)},
+        tire_deg={d: rng.choice([0.01, 0.015, 0.03, 0.05, 0.06, 0.09, 0.15]) for d in drv if d not in ('BOR', 'XXX')},
+        driver_variance={d: 0.05 + 0.25 * rng.random() for d in drv if d not in ('OCO',)},
+        driver_dnf_rates={d: (0.02 + 0.1 * rng.random()) / 57 for d in drv if d not in ('BEA', 'VER')},
+    )
+    cases.append(het)
+
+    # DMP / WET: rain conditions (INTERMEDIATE / WET start tyres, no 2-compound rule).
+    dmp = canonical_case('DMP', 57, 'Bahrain', 1000, 8, seed=11)
+    dmp['track_condition'] = 'damp'
+    dmp['config'].update(sc_probability=0.04, vsc_probability=0.04, red_flag_probability=0.02)
+    cases.append(dmp)
+    wet = canonical_case('WET', 44, 'Belgium', 1000, 8, seed=12)
+    wet['track_condition'] = 'wet'
+    wet['config'].update(sc_probability=0.04, vsc_probability=0.04, red_flag_probability=0.02)
+    cases.append(wet)
+
+    # N10: small field (10 cars), long race so backmarkers get lapped-distance gaps
+    # and a retired car can sit between runners in the overtake sort (Q15).
+    d10 = list(DRIVER_TEAMS.keys())[::2]
+    n10 = dict(
+        name='N10', n_sims=1500, n_orders=256, n_trace=16, seed=5, track_condition='dry',
+        config=config_dict(72, 20.0, 0.5),
+        grid_probs=elo_grid(d10),
+        base_pace={d: 80.0 + 0.6 * i for i, d in enumerate(d10)},
+        tire_deg={d: 0.04 + 0.004 * i for i, d in enumerate(d10)},
+        driver_variance={d: 0.3 for d in d10},
+        driver_dnf_rates={d: 0.6 / 72 for d in d10},
+    )
+    cases.append(n10)
+    return cases
+
+
+class TracingSimulator(RaceSimulator):
+    """Reference simulator + observers.  Only wraps calls; draws no randomness."""
+
+    def __init__(self, config, drivers, n_trace, n_orders):
+        super().__init__(config)
+        self.drivers = drivers
+        self.index = {d: i for i, d in enumerate(drivers)}
+        self.n_trace = n_trace
+        self.n_orders = n_orders
+        self.sim = -1
+        self.grids, self.orders, self.traces = [], [], []
+        self._cur = None
+
+    def simulate_race(self, grid, *a, **k):
+        self.sim += 1
+        if self.sim < self.n_orders:
+            self.grids.append([self.index[str(d)] for d in grid])
+        self._cur = [] if self.sim < self.n_trace else None
+        res = super().simulate_race(grid, *a, **k)
+        if self.sim < self.n_orders:
+            self.orders.append([self.index[str(d)] for d, _ in res])
+        if self._cur is not None:
+            self.traces.append(self._cur)
+        self._cur = None
+        return res
+
+    def _update_positions(self, cars, lap=3, drs_disabled=False):
+        cars = super()._update_positions(cars, lap=lap, drs_disabled=drs_disabled)
+        if self._cur is not None:
+            n = len(self.drivers)
+            snap = dict(cum=np.zeros(n), tbl=np.zeros(n), last=np.zeros(n), age=np.zeros(n, np.int16),
+                        comp=np.zeros(n, np.uint8), used=np.zeros(n, np.uint8), dnf=np.zeros(n, np.uint8),
+                        drs=np.zeros(n, np.uint8), dnf_lap=np.zeros(n, np.int16))
+            for c in cars:
+                i = self.index[str(c.driver)]
+                snap['cum'][i] = c.cumulative_time
+                snap['tbl'][i] = c.time_behind_leader
+                snap['last'][i] = c.last_lap_time
+                snap['age'][i] = c.tire_age
+                snap['comp'][i] = COMPOUND_ID[c.tire_compound]
+                snap['used'][i] = sum(1 << COMPOUND_ID[x] for x in c.used_compounds)
+                snap['dnf'][i] = c.dnf
+                snap['drs'][i] = c.drs_enabled
+                snap['dnf_lap'][i] = c.lap if c.dnf else 0
+            self._cur.append(snap)
+        return cars
+
+
+def run_case(case):
+    cfg = RaceConfig(**case['config'])
+    drivers = list(case['grid_probs'].keys())
+    n = len(drivers)
+    sim = TracingSimulator(cfg, drivers, case['n_trace'], case['n_orders'])
+    t0 = time.time()
+    probs = sim.run_monte_carlo(
+        case['n_sims'], case['grid_probs'], case['base_pace'], case['tire_deg'],
+        case['driver_variance'], case['driver_dnf_rates'], seed=case['seed'],
+        track_condition=case['track_condition'])
+    dt = time.time() - t0
+    hist = np.zeros((n, n), np.int64)
+    for d, dist in probs.items():
+        for pos, p in dist.items():
+            c = p * case['n_sims']
+            assert abs(c - round(c)) < 1e-6
+            hist[sim.index[str(d)], pos - 1] = int(round(c))
+    assert hist.sum() == n * case['n_sims']
+    L = case['config']['total_laps']
+    out = dict(hist=hist, orders=np.array(sim.orders, np.uint8), grids=np.array(sim.grids, np.uint8))
+    for key in ('cum', 'tbl', 'last', 'age', 'comp', 'used', 'dnf', 'drs', 'dnf_lap'):
+        arr = np.array([[snap[key] for snap in tr] for tr in sim.traces])
+        assert arr.shape == (case['n_trace'], L, n), arr.shape
+        out['trace_' + key] = arr
+    np.savez_compressed(os.path.join(HERE, case['name'] + '.npz'), **out)
+    print(f"{case['name']}: {case['n_sims']} sims in {dt:.1f}s ({case['n_sims']/dt:.0f}/s); "
+          f"wins {[int(x) for x in hist[:6, 0]]}", flush=True)
+    return dt
+
+
+def mt_streams():
+    """G4: pins the RNG replay (CPython `random`, numpy legacy RandomState)."""
+    out = {}
+    for seed in (42, 0, 2 ** 32 - 1):
+        random.seed(seed)
+        out[f'py_random_{seed}'] = np.array([random.random() for _ in range(4096)])
+        np.random.seed(seed)
+        out[f'np_sample_{seed}'] = np.array([np.random.random_sample() for _ in range(1024)])
+        np.random.seed(seed)
+        out[f'np_normal_{seed}'] = np.array([np.random.normal(0, 1.0) for _ in range(1025)])
+        # interleaved choice / normal exactly as the simulator issues them: the
+        # gauss cache must survive the choice() calls.
+        np.random.seed(seed)
+        mix = []
+        p = np.array([0.1, 0.0, 0.25, 0.05, 0.6])
+        for i in range(600):
+            mix.append(float(np.random.choice(5, p=p)))
+            mix.append(np.random.normal(0, 0.18))
+            if i % 3 == 0:
+                mix.append(np.random.normal(0, 1.5))
+        out[f'np_mix_{seed}'] = np.array(mix)
+    np.savez_compressed(os.path.join(HERE, 'mt_streams.npz'), **out)
+
+
+def sample_grids(cases):
+    """G5: 1000 `_sample_grid` results for the Elo grid and the one-hot+penalty grid."""
+    out = {}
+    for case in cases:
+        if case['name'] not in ('S60', 'HET', 'N10'):
+            continue
+        sim = RaceSimulator(RaceConfig(**case['config']))
+        drivers = list(case['grid_probs'].keys())
+        idx = {d: i for i, d in enumerate(drivers)}
+        np.random.seed(99)
+        random.seed(99)
+        out[case['name']] = np.array(
+            [[idx[str(d)] for d in sim._sample_grid(case['grid_probs'])] for _ in range(1000)], np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'sample_grid.npz'), **out)
+
+
+def misc():
+    """G6: host-side helpers either side of the path ("next" rows of SURVEY 8f)."""
+    drivers = list(DRIVER_TEAMS.keys())
+    ratings = {d: 1700.0 - 20.0 * i for i, d in enumerate(drivers)}
+    p = make_predictor(ratings)
+    feats = {d: {'teammate_delta': 0.3 * ((i % 3) - 1), 'form_score': 0.1 * (i % 5) - 0.2,
+                 'circuit_affinity': 0.05 * (i % 4)} for i, d in enumerate(drivers)}
+    out = dict(
+        drivers=drivers, ratings=ratings, features=feats,
+        pole_probs=p.elo_system.predict_quali_probs(drivers),
+        quali_plain=p._predict_quali(drivers, {}),
+        quali_feat=p._predict_quali(drivers, feats),
+        penalties={'VER': 'engine', 'NOR': 5, 'HAM': 'full_pu', 'ALB': 'gearbox'},
+    )
+    out['quali_penalised'] = p._adjust_for_penalties(out['quali_plain'], out['penalties'])
+    out['apply_grid_penalties'] = p.apply_grid_penalties(
+        {d: i + 1 for i, d in enumerate(drivers)}, out['penalties'])
+    rc = p._create_race_config(p._get_circuit_info('Bahrain Grand Prix'))
+    out['race_config_bahrain'] = [rc.total_laps, rc.pit_loss, rc.overtake_delta, rc.sc_probability,
+                                  rc.vsc_probability, rc.red_flag_probability, rc.drs_delta]
+    rc2 = p._create_race_config(p._get_circuit_info('Nowhere GP'))
+    out['race_config_fallback'] = [rc2.total_laps, rc2.pit_loss, rc2.overtake_delta, rc2.drs_zones]
+    uni = {d: 1.0 / 20 for d in drivers}
+    out['brier_uniform'] = float(brier_score([uni], ['VER']))
+    preds = [out['pole_probs'], uni, {d: (0.9 if d == 'NOR' else 0.1 / 19) for d in drivers}]
+    acts = ['VER', None, 'NOR']
+    out['brier_inputs'] = dict(preds=preds, actuals=acts)
+    out['brier_mixed'] = float(brier_score(preds, acts))
+    pod_pred = [{'podium_probabilities': {d: 1.0 / (i + 1) for i, d in enumerate(drivers)}},
+                {'podium_probabilities': {d: float(i) for i, d in enumerate(drivers)}}]
+    pod_act = [{'podium': ['VER', 'NOR', 'HAM']}, {'podium': ['BEA', 'OCO', 'VER']}]
+    out['podium_inputs'] = dict(preds=pod_pred, actuals=pod_act)
+    out['podium_accuracy'] = float(podium_accuracy(pod_pred, pod_act))
+    # Elo update known answers
+    e = F1EloSystem()
+    e.set_recency_weight(0, 5, 24)
+    e.update_quali_ratings([(d, 80.0 + 0.1 * ((i * 7) % 20)) for i, d in enumerate(drivers)])
+    e.set_recency_weight(1)
+    e.update_race_ratings([(d, ((i * 3) % 20) + 1) for i, d in enumerate(drivers)])
+    out['elo_after'] = e.ratings
+    out['circuits'] = CIRCUITS
+    out['driver_teams'] = DRIVER_TEAMS
+    out['dnf_rates'] = DEFAULT_DNF_RATES
+    out['tire_compounds'] = TIRE_COMPOUNDS
+    with open(os.path.join(HERE, 'misc.json'), 'w') as f:
+        json.dump(json.loads(json.dumps(out, default=float)), f, indent=0)
+
+
+def ref_stat(case, seeds, n_each):
+    """Big-N reference histogram (one process per seed) for the statistical link."""
+    import multiprocessing as mp
+    with mp.Pool(min(len(seeds), 8)) as pool:
+        hs = pool.starmap(_ref_stat_one, [(case, s, n_each) for s in seeds])
+    np.savez_compressed(os.path.join(HERE, f"ref_stat_{case['name']}.npz"),
+                        hist=np.sum(hs, axis=0), per_seed=np.array(hs), seeds=np.array(seeds),
+                        n_each=n_each)
+    print(f"ref_stat {case['name']}: {len(seeds)}x{n_each}", flush=True)
+
+
+def _ref_stat_one(case, seed, n_each):
+    cfg = RaceConfig(**case['config'])
+    drivers = list(case['grid_probs'].keys())
+    idx = {d: i for i, d in enumerate(drivers)}
+    probs = RaceSimulator(cfg).run_monte_carlo(
+        n_each, case['grid_probs'], case['base_pace'], case['tire_deg'], case['driver_variance'],
+        case['driver_dnf_rates'], seed=seed, track_condition=case['track_condition'])
+    h = np.zeros((len(drivers), len(drivers)), np.int64)
+    for d, dist in probs.items():
+        for pos, p in dist.items():
+            h[idx[str(d)], pos - 1] = int(round(p * n_each))
+    return h
+
+
+def main():
+    what = sys.argv[1:] or ['cases', 'streams', 'grids', 'misc']
+    cases = build_cases()
+    if 'cases' in what:
+        meta = dict(
+            generated_with=dict(python=sys.version.split()[0], numpy=np.__version__, hashseed=0),
+            set_pop=dict(SOFT_HARD=({'SOFT', 'MEDIUM', 'HARD'} - {'MEDIUM'}).pop(),
+                         MEDIUM_HARD=({'SOFT', 'MEDIUM', 'HARD'} - {'SOFT'}).pop(),
+                         SOFT_MEDIUM=({'SOFT', 'MEDIUM', 'HARD'} - {'HARD'}).pop()),
+            compound_id=COMPOUND_ID,
+            cases={c['name']: c for c in cases},
+        )
+        with open(os.path.join(HERE, 'cases.json'), 'w') as f:
+            json.dump(meta, f, indent=0)
+        for c in cases:
+            run_case(c)
+    if 'streams' in what:
+        mt_streams()
+    if 'grids' in what:
+        sample_grids(cases)
+    if 'misc' in what:
+        misc()
+    if 'stat' in what:
+        by = {c['name']: c for c in cases}
+        ref_stat(by['S60'], list(range(101, 109)), 25000)
+        ref_stat(by['S78'], list(range(201, 209)), 12500)
+
+
+if __name__ == '__main__':
+    main()
