@@ -1,0 +1,133 @@
+/* mcgp.h -- C ABI of the MI355X (gfx950) Monte Carlo race-simulation engine.
+ *
+ * libmcgp_hip.so is the drop-in for the reference's hot path
+ *     RaceSimulator(config).run_monte_carlo(...)      reference src/simulation.py:56-100
+ * (sole call site: reference src/predictor.py:264,283-291).  The reference has no
+ * FFI of its own (it is pure Python); these entry points are what a ctypes
+ * binding of that method binds -- see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++ / torch types; caller owns every buffer and
+ *     the library keeps no pointer past return;
+ *   - every function returns 0 on success or a negative MCGP_E_* code and never
+ *     throws or aborts; mcgp_last_error() gives the thread-local message;
+ *   - blocking calls, re-entrant for distinct devices (one cached context per
+ *     device, guarded by a mutex);
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with MCGP_E_NO_DEVICE;
+ *   - no RNG state: every random draw is a pure function of
+ *     (seed, sim_offset + i, lap, purpose, index) (Philox4x32-10), so any split
+ *     of [0, N) over calls / devices / ranks sums to the same histogram.
+ */
+#ifndef MCGP_H
+#define MCGP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCGP_ABI_VERSION 1
+#define MCGP_MAX_CARS 32
+#define MCGP_MAX_LAPS 1000
+
+enum {
+    MCGP_OK = 0,
+    MCGP_E_BAD_ARG = -1,    /* NULL pointer, n out of [1, 32], laps out of [1, 1000], bad enum */
+    MCGP_E_NO_DEVICE = -2,  /* no HIP device / device index out of range */
+    MCGP_E_HIP = -3,        /* a HIP runtime call failed (message has the HIP error string) */
+    MCGP_E_NOMEM = -4       /* device or host allocation failed */
+};
+
+/* tyre compounds (reference src/config.py:45-51) and track condition
+ * (run_monte_carlo argument `track_condition`, reference src/simulation.py:68) */
+enum { MCGP_SOFT = 0, MCGP_MEDIUM = 1, MCGP_HARD = 2, MCGP_INTERMEDIATE = 3, MCGP_WET = 4 };
+enum { MCGP_DRY = 0, MCGP_DAMP = 1, MCGP_WET_TRACK = 2 };
+
+/* RaceConfig -- replaces the dataclass at reference src/simulation.py:37-52, with
+ * the dict-valued fields resolved to dense tables by the caller (the host shim):
+ *   tire_compounds[c].get('pace_delta', 0) / .get('deg_rate', 0.05) / .get('optimal_laps', 30)
+ *   (reference :317-325, :454-455).
+ * pop_*: outcome of `available.pop()` on the two-element set at reference :486,488,
+ * which depends on PYTHONHASHSEED in the reference; explicit here. */
+typedef struct mcgp_config {
+    int32_t total_laps;
+    int32_t track_condition;
+    double pit_loss;
+    double overtake_delta;
+    double sc_probability;
+    double vsc_probability;
+    double red_flag_probability;
+    double drs_delta;
+    double dirty_air_threshold;
+    double dirty_air_penalty;
+    double comp_pace_delta[5];
+    double comp_deg_rate[5];
+    int32_t comp_optimal_laps[5];
+    int32_t pop_soft_hard;      /* compound id taken from {SOFT, HARD}   */
+    int32_t pop_medium_hard;    /* compound id taken from {MEDIUM, HARD} */
+} mcgp_config;
+
+/* Per-driver inputs as structure-of-arrays of length n; index = position of the driver
+ * in grid_probs' key order.  Replaces the five dict arguments of run_monte_carlo
+ * (reference :62-66) with their .get() defaults resolved:
+ *   base_pace     base_pace.get(d, 90.0)                           :202,294,514
+ *   tire_deg      tire_deg.get(d, 0.05)                            :203,295,514
+ *   tire_deg_pit  tire_deg.get(d, 0.0)                             :458
+ *   variance      driver_variance.get(d, 0.15)                     :204,296
+ *   team_dnf      config.dnf_rates.get(driver_teams.get(d,'Unknown'), 0.002)   :286
+ *   lap_dnf       driver_dnf_rates.get(d, team_dnf[d])             :190-193 */
+typedef struct mcgp_drivers {
+    const double *base_pace;
+    const double *tire_deg;
+    const double *tire_deg_pit;
+    const double *variance;
+    const double *team_dnf;
+    const double *lap_dnf;
+} mcgp_drivers;
+
+int32_t mcgp_abi_version(void);
+int32_t mcgp_device_count(void);          /* number of HIP devices, 0 if none */
+const char *mcgp_last_error(void);        /* thread-local, never NULL */
+
+/* run_monte_carlo (reference :59-100) on `device`.
+ *   grid_probs  n x n row-major [driver][grid slot]     (grid_probs dict, reference :62)
+ *   hist_out    n x n row-major [driver][position-1] counts; ACCUMULATED into
+ *               (caller zeroes); divide by the total simulation count for the
+ *               probabilities of reference :97-100
+ *   orders_out  optional, [n_sims][n]: driver index classified p-th in simulation
+ *               sim_offset+i; NULL to skip (histogram-only mode writes no per-sim bytes)
+ * Host buffers in, host buffers out. */
+int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs,
+                 uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
+                 int32_t device, uint64_t *hist_out, uint8_t *orders_out);
+
+/* Same computation with DEVICE-resident outputs, asynchronous on `stream`
+ * (a hipStream_t, NULL = the device's default stream): d_hist (n*n uint64, device,
+ * accumulated) and optional d_orders (n_sims*n uint8, device).  Used by the
+ * multi-GPU path (RCCL all-reduce of d_hist) and by bench.py.  The small
+ * parameter block is uploaded on the same stream before the launch. */
+int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs,
+                        uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
+                        int32_t device, void *stream, uint64_t *d_hist, uint8_t *d_orders);
+
+/* simulate_race (reference :147-242): one race from a FIXED starting grid
+ * (grid[p] = driver index on slot p), simulation id sim_id.  order_out[p] = driver
+ * index classified p-th.  Bit-identical to what mcgp_run computes for a simulation
+ * whose sampled grid equals `grid`. */
+int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, const uint8_t *grid,
+                           uint32_t n, uint64_t sim_id, uint64_t seed, int32_t device,
+                           uint8_t *order_out);
+
+/* Measurement hooks (bench.py): duration in ms of the most recent race kernel
+ * launched by this thread's last mcgp_run / mcgp_run_device on `device`, from
+ * hipEvents recorded on the launch stream (synchronises on the stop event);
+ * and the launch geometry that call used. */
+int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out);
+int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads,
+                              uint32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""ctypes binding of libmcgp_hip.so (C ABI: include/mcgp.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc, and
+if that fails, or no HIP device is visible, the error is raised to the caller.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_PKG, 'csrc')
+LIB_PATH = os.path.join(_PKG, 'libmcgp_hip.so')
+
+MAX_CARS = 32
+MAX_LAPS = 1000
+ABI_VERSION = 1
+
+COMPOUNDS = ('SOFT', 'MEDIUM', 'HARD', 'INTERMEDIATE', 'WET')
+COMPOUND_ID = {c: i for i, c in enumerate(COMPOUNDS)}
+TRACK_ID = {'dry': 0, 'damp': 1, 'wet': 2}
+
+
+class McgpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'mcgp error {code}: {msg}')
+        self.code = code
+
+
+class McgpConfig(C.Structure):
+    _fields_ = [
+        ('total_laps', C.c_int32), ('track_condition', C.c_int32),
+        ('pit_loss', C.c_double), ('overtake_delta', C.c_double),
+        ('sc_probability', C.c_double), ('vsc_probability', C.c_double),
+        ('red_flag_probability', C.c_double), ('drs_delta', C.c_double),
+        ('dirty_air_threshold', C.c_double), ('dirty_air_penalty', C.c_double),
+        ('comp_pace_delta', C.c_double * 5), ('comp_deg_rate', C.c_double * 5),
+        ('comp_optimal_laps', C.c_int32 * 5),
+        ('pop_soft_hard', C.c_int32), ('pop_medium_hard', C.c_int32),
+    ]
+
+
+class McgpDrivers(C.Structure):
+    _fields_ = [(k, C.POINTER(C.c_double)) for k in
+                ('base_pace', 'tire_deg', 'tire_deg_pit', 'variance', 'team_dnf', 'lap_dnf')]
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ('mcgp_hip.hip', 'race_kernel.hip.h', 'normal_table.h')]
+    srcs.append(os.path.join(os.path.dirname(_PKG), 'include', 'mcgp.h'))
+    stale = (not os.path.exists(LIB_PATH)
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
+    if force or stale:
+        subprocess.check_call(['make', '-C', CSRC, '-s', '-B'])
+    return LIB_PATH
+
+
+_lib = None
+
+EXPORTS = ('mcgp_abi_version', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
+           'mcgp_simulate_race', 'mcgp_last_kernel_ms', 'mcgp_last_launch_info')
+
+
+def lib():
+    """Load the library (building it if the sources are newer); raises if impossible."""
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.mcgp_abi_version.restype = C.c_int32
+        L.mcgp_device_count.restype = C.c_int32
+        L.mcgp_last_error.restype = C.c_char_p
+        dp = C.POINTER(C.c_double)
+        L.mcgp_run.restype = C.c_int32
+        L.mcgp_run.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), dp, C.c_uint32, C.c_uint64,
+                               C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
+        L.mcgp_run_device.restype = C.c_int32
+        L.mcgp_run_device.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), dp, C.c_uint32, C.c_uint64,
+                                      C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcgp_simulate_race.restype = C.c_int32
+        L.mcgp_simulate_race.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), C.POINTER(C.c_uint8),
+                                         C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint8)]
+        L.mcgp_last_kernel_ms.restype = C.c_int32
+        L.mcgp_last_kernel_ms.argtypes = [C.c_int32, C.POINTER(C.c_float)]
+        L.mcgp_last_launch_info.restype = C.c_int32
+        L.mcgp_last_launch_info.argtypes = [C.c_int32] + [C.POINTER(C.c_uint32)] * 3
+        if L.mcgp_abi_version() != ABI_VERSION:
+            raise McgpError(-1, f'ABI version {L.mcgp_abi_version()} != {ABI_VERSION}')
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise McgpError(rc, lib().mcgp_last_error().decode('utf-8', 'replace'))

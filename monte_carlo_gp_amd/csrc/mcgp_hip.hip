@@ -1,0 +1,375 @@
+// mcgp_hip.hip -- C-ABI (include/mcgp.h) over the gfx950 race kernel.
+//
+// Host side of the drop-in boundary: validates arguments, folds the reference's
+// per-race constants into the kernel's parameter block, owns one cached context
+// per HIP device (parameter buffer, scratch histogram, events) and launches
+// race_kernel.  No CPU compute path exists here: without a HIP device every
+// compute entry point returns MCGP_E_NO_DEVICE.
+#include "../../include/mcgp.h"
+#include "normal_table.h"
+#include "race_kernel.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? MCGP_E_NOMEM : MCGP_E_HIP,                    \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+constexpr int kParamSlots = 4;
+
+struct DeviceCtx {
+    std::mutex mu;
+    bool ready = false;
+    int cu_count = 0;
+    size_t lds_per_block = 0;
+    // Parameter blocks: a small ring so that a launch never rewrites a block an
+    // earlier, still running launch reads; an unchanged problem re-uses its block
+    // with no upload at all (bench.py's steady state).
+    struct Slot {
+        mcgp::KParams *dev = nullptr;
+        mcgp::KParams *host = nullptr;        // pinned copy of what `dev` holds
+        hipEvent_t done = nullptr;            // recorded after the last launch that reads `dev`
+        bool used = false;
+    } slot[kParamSlots];
+    int next_slot = 0;
+    unsigned long long *d_hist = nullptr;     // scratch for the host-buffer entry points
+    uint8_t *d_grid = nullptr;                // fixed grid for mcgp_simulate_race
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    uint32_t last_grid = 0, last_block = 0, last_lds = 0;
+};
+
+constexpr int kMaxDevices = 64;
+DeviceCtx g_ctx[kMaxDevices];
+
+int device_count_nothrow()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ensure_ctx(int device, DeviceCtx **out)
+{
+    const int nd = device_count_nothrow();
+    if (nd <= 0) return fail(MCGP_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= nd || device >= kMaxDevices)
+        return fail(MCGP_E_NO_DEVICE, "device index out of range");
+    DeviceCtx &c = g_ctx[device];
+    if (!c.ready) {
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        c.cu_count = prop.multiProcessorCount;
+        c.lds_per_block = prop.sharedMemPerBlock;       // 160 KiB on gfx950
+        for (auto &sl : c.slot) {
+            HIP_TRY(hipMalloc(&sl.dev, sizeof(mcgp::KParams)));
+            HIP_TRY(hipHostMalloc(&sl.host, sizeof(mcgp::KParams)));
+            HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMalloc(&c.d_hist, sizeof(unsigned long long) * MCGP_MAX_CARS * MCGP_MAX_CARS));
+        HIP_TRY(hipMalloc(&c.d_grid, MCGP_MAX_CARS));
+        HIP_TRY(hipEventCreate(&c.ev_start));
+        HIP_TRY(hipEventCreate(&c.ev_stop));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
+        c.ready = true;
+    }
+    *out = &c;
+    return MCGP_OK;
+}
+
+// u < p for u = w / 2^32  <=>  w < ceil(p * 2^32)   (p * 2^32 is exact in binary64)
+uint64_t threshold(double p)
+{
+    if (!(p > 0.0)) return 0;                  // also NaN: `u < nan` is false
+    const double x = p * 4294967296.0;
+    if (x >= 4294967296.0) return 4294967296ull;
+    return (uint64_t)std::ceil(x);
+}
+
+int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs, uint32_t n,
+                 mcgp::KParams *kp)
+{
+    if (!cfg || !drv) return fail(MCGP_E_BAD_ARG, "cfg / drv is NULL");
+    if (n < 1 || n > MCGP_MAX_CARS) return fail(MCGP_E_BAD_ARG, "n must be in [1, 32]");
+    if (cfg->total_laps < 1 || cfg->total_laps > MCGP_MAX_LAPS)
+        return fail(MCGP_E_BAD_ARG, "total_laps must be in [1, 1000]");
+    if (cfg->track_condition < MCGP_DRY || cfg->track_condition > MCGP_WET_TRACK)
+        return fail(MCGP_E_BAD_ARG, "track_condition must be 0 (dry), 1 (damp) or 2 (wet)");
+    if (cfg->pop_soft_hard != MCGP_SOFT && cfg->pop_soft_hard != MCGP_HARD)
+        return fail(MCGP_E_BAD_ARG, "pop_soft_hard must be SOFT or HARD");
+    if (cfg->pop_medium_hard != MCGP_MEDIUM && cfg->pop_medium_hard != MCGP_HARD)
+        return fail(MCGP_E_BAD_ARG, "pop_medium_hard must be MEDIUM or HARD");
+    if (!drv->base_pace || !drv->tire_deg || !drv->tire_deg_pit || !drv->variance || !drv->team_dnf ||
+        !drv->lap_dnf)
+        return fail(MCGP_E_BAD_ARG, "a per-driver array is NULL");
+    std::memset(kp, 0, sizeof(*kp));
+    kp->n = (int32_t)n;
+    kp->total_laps = cfg->total_laps;
+    kp->track = cfg->track_condition;
+    kp->pop_sh = cfg->pop_soft_hard;
+    kp->pop_mh = cfg->pop_medium_hard;
+    kp->pit_loss = cfg->pit_loss;
+    kp->overtake_delta = cfg->overtake_delta;
+    kp->drs_delta = cfg->drs_delta;
+    kp->dirty_thr = cfg->dirty_air_threshold;
+    kp->dirty_pen = cfg->dirty_air_penalty;
+    kp->t_red = threshold(cfg->red_flag_probability);
+    kp->t_sc = threshold(cfg->sc_probability);
+    kp->t_vsc = threshold(cfg->vsc_probability);
+    kp->t_vsc_tire = threshold(0.3);                                   // reference :392
+    for (int c = 0; c < 5; ++c) {
+        kp->comp_deg[c] = cfg->comp_deg_rate[c];
+        kp->comp_delta[c] = cfg->comp_pace_delta[c];
+        if (cfg->comp_optimal_laps[c] < 0 || cfg->comp_optimal_laps[c] > 50000)
+            return fail(MCGP_E_BAD_ARG, "comp_optimal_laps out of range");
+    }
+    for (uint32_t d = 0; d < n; ++d) {
+        const double deg = drv->tire_deg[d];
+        kp->base_pace[d] = drv->base_pace[d];
+        kp->factor[d] = deg > 0 ? deg / 0.05 : 1.0;                    // reference :321
+        kp->tire_deg[d] = deg;
+        kp->variance[d] = drv->variance[d];
+        kp->t_dnf1[d] = threshold(drv->team_dnf[d] * 4.0);             // reference :282,286-287
+        kp->t_dnf[d] = threshold(drv->lap_dnf[d]);
+        const double pit_deg = drv->tire_deg_pit[d];
+        for (int c = 0; c < 5; ++c) {
+            int opt = cfg->comp_optimal_laps[c];                       // reference :455-462
+            if (pit_deg > 0.05) opt = (int)((double)opt * 0.85);
+            else if (pit_deg < 0.02) opt = (int)((double)opt * 1.1);
+            kp->opt_laps[d * mcgp::kCompStride + c] = (uint16_t)opt;
+        }
+    }
+    if (grid_probs)
+        for (uint32_t d = 0; d < n; ++d)
+            for (uint32_t s = 0; s < n; ++s) {
+                const double p = grid_probs[(size_t)d * n + s];
+                if (!(p >= 0.0)) return fail(MCGP_E_BAD_ARG, "grid_probs has a negative or NaN entry");
+                kp->grid_probs[(size_t)d * n + s] = p;
+            }
+    static_assert(sizeof(mcgp_normal_table_bits) == sizeof(kp->normal_bits), "normal table size");
+    std::memcpy(kp->normal_bits, mcgp_normal_table_bits, sizeof(kp->normal_bits));
+    return MCGP_OK;
+}
+
+// Launch geometry: as many waves per block as LDS allows (one block per CU),
+// persistent blocks striding over batches of blockDim.x simulations.
+void launch_geometry(const DeviceCtx &c, uint32_t n, uint64_t n_sims, uint32_t *grid, uint32_t *block,
+                     uint32_t *lds)
+{
+    const size_t per_wave = 64 * mcgp::per_thread_lds_bytes((int)n);
+    int waves = (int)((c.lds_per_block - mcgp::kSharedTableBytes) / per_wave);
+    if (waves > 8) waves = 8;
+    if (waves < 1) waves = 1;
+    int blocks_per_cu = 1;
+    if (const char *e = std::getenv("MCGP_WAVES_PER_BLOCK")) {
+        const int w = std::atoi(e);
+        if (w >= 1 && w <= waves) waves = w;
+    }
+    {
+        const size_t blk = mcgp::kSharedTableBytes + (size_t)waves * per_wave;
+        blocks_per_cu = (int)(c.lds_per_block / blk);
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+        if (blocks_per_cu * waves > 32) blocks_per_cu = 32 / waves;
+    }
+    uint32_t threads = (uint32_t)waves * 64u;
+    if (n_sims < threads) threads = (uint32_t)(((n_sims + 63) / 64) * 64);
+    if (threads == 0) threads = 64;
+    const uint64_t n_batches = (n_sims + threads - 1) / threads;
+    uint64_t g = (uint64_t)c.cu_count * (uint64_t)blocks_per_cu;
+    if (g > n_batches) g = n_batches;
+    if (g < 1) g = 1;
+    *grid = (uint32_t)g;
+    *block = threads;
+    *lds = (uint32_t)(mcgp::kSharedTableBytes + (size_t)threads * mcgp::per_thread_lds_bytes((int)n));
+}
+
+int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
+           hipStream_t stream, unsigned long long *d_hist, uint8_t *d_orders, const uint8_t *d_fixed_grid)
+{
+    if (n_sims == 0) return MCGP_OK;
+    uint32_t grid, block, lds;
+    launch_geometry(c, (uint32_t)kp.n, n_sims, &grid, &block, &lds);
+    const uint64_t n_batches = (n_sims + block - 1) / block;
+    if (n_batches > 0xffffffffull) return fail(MCGP_E_BAD_ARG, "n_sims too large for one launch");
+    DeviceCtx::Slot *sl = nullptr;
+    for (auto &cand : c.slot)
+        if (cand.used && std::memcmp(cand.host, &kp, sizeof(kp)) == 0) { sl = &cand; break; }
+    if (!sl) {
+        sl = &c.slot[c.next_slot];
+        c.next_slot = (c.next_slot + 1) % kParamSlots;
+        if (sl->used) HIP_TRY(hipEventSynchronize(sl->done));   // its last reader has finished
+        std::memcpy(sl->host, &kp, sizeof(kp));
+        sl->used = true;
+        HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, sizeof(kp), hipMemcpyHostToDevice, stream));
+    }
+    HIP_TRY(hipEventRecord(c.ev_start, stream));
+    hipLaunchKernelGGL(mcgp::race_kernel, dim3(grid), dim3(block), lds, stream, sl->dev, n_sims,
+                       sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32), d_hist, d_orders, d_fixed_grid,
+                       (uint32_t)n_batches);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c.ev_stop, stream));
+    HIP_TRY(hipEventRecord(sl->done, stream));
+    c.timed = true;
+    c.last_grid = grid;
+    c.last_block = block;
+    c.last_lds = lds;
+    return MCGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mcgp_abi_version(void) { return MCGP_ABI_VERSION; }
+
+int32_t mcgp_device_count(void) { return device_count_nothrow(); }
+
+const char *mcgp_last_error(void) { return g_err.c_str(); }
+
+int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs,
+                        uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed, int32_t device,
+                        void *stream, uint64_t *d_hist, uint8_t *d_orders)
+{
+    if (!grid_probs || !d_hist) return fail(MCGP_E_BAD_ARG, "grid_probs / d_hist is NULL");
+    mcgp::KParams *kp = new (std::nothrow) mcgp::KParams;
+    if (!kp) return fail(MCGP_E_NOMEM, "host allocation failed");
+    int rc = build_params(cfg, drv, grid_probs, n, kp);
+    DeviceCtx *c = nullptr;
+    if (rc == MCGP_OK) rc = ensure_ctx(device, &c);
+    if (rc == MCGP_OK) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) rc = fail(MCGP_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        else rc = launch(*c, *kp, n_sims, sim_offset, seed, (hipStream_t)stream,
+                         reinterpret_cast<unsigned long long *>(d_hist), d_orders, nullptr);
+    }
+    delete kp;
+    return rc;
+}
+
+int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs, uint32_t n,
+                 uint64_t n_sims, uint64_t sim_offset, uint64_t seed, int32_t device, uint64_t *hist_out,
+                 uint8_t *orders_out)
+{
+    if (!grid_probs || !hist_out) return fail(MCGP_E_BAD_ARG, "grid_probs / hist_out is NULL");
+    mcgp::KParams *kp = new (std::nothrow) mcgp::KParams;
+    if (!kp) return fail(MCGP_E_NOMEM, "host allocation failed");
+    int rc = build_params(cfg, drv, grid_probs, n, kp);
+    DeviceCtx *c = nullptr;
+    if (rc == MCGP_OK) rc = ensure_ctx(device, &c);
+    if (rc != MCGP_OK) { delete kp; return rc; }
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto body = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        const size_t hist_bytes = sizeof(unsigned long long) * n * n;
+        HIP_TRY(hipMemsetAsync(c->d_hist, 0, hist_bytes, nullptr));
+        // per-simulation orders are staged in chunks so the device buffer stays bounded
+        const uint64_t chunk = orders_out ? (uint64_t)(1u << 22) : n_sims;
+        uint8_t *d_orders = nullptr;
+        if (orders_out && n_sims) HIP_TRY(hipMalloc(&d_orders, (size_t)(chunk < n_sims ? chunk : n_sims) * n));
+        int r = MCGP_OK;
+        for (uint64_t done = 0; done < n_sims && r == MCGP_OK; done += chunk) {
+            const uint64_t m = (n_sims - done) < chunk ? (n_sims - done) : chunk;
+            r = launch(*c, *kp, m, sim_offset + done, seed, nullptr, c->d_hist, d_orders, nullptr);
+            if (r == MCGP_OK && d_orders) {
+                hipError_t e = hipMemcpy(orders_out + (size_t)done * n, d_orders, (size_t)m * n, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) r = fail(MCGP_E_HIP, std::string("hipMemcpy(orders): ") + hipGetErrorString(e));
+            }
+        }
+        if (d_orders) (void)hipFree(d_orders);
+        if (r != MCGP_OK) return r;
+        unsigned long long h[MCGP_MAX_CARS * MCGP_MAX_CARS];
+        HIP_TRY(hipMemcpy(h, c->d_hist, hist_bytes, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n * n; ++i) hist_out[i] += h[i];
+        return MCGP_OK;
+    };
+    rc = body();
+    delete kp;
+    return rc;
+}
+
+int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, const uint8_t *grid, uint32_t n,
+                           uint64_t sim_id, uint64_t seed, int32_t device, uint8_t *order_out)
+{
+    if (!grid || !order_out) return fail(MCGP_E_BAD_ARG, "grid / order_out is NULL");
+    if (n >= 1 && n <= MCGP_MAX_CARS) {
+        uint32_t seen = 0;
+        for (uint32_t p = 0; p < n; ++p) {
+            if (grid[p] >= n || (seen >> grid[p] & 1u)) return fail(MCGP_E_BAD_ARG, "grid is not a permutation of 0..n-1");
+            seen |= 1u << grid[p];
+        }
+    }
+    mcgp::KParams *kp = new (std::nothrow) mcgp::KParams;
+    if (!kp) return fail(MCGP_E_NOMEM, "host allocation failed");
+    int rc = build_params(cfg, drv, nullptr, n, kp);
+    DeviceCtx *c = nullptr;
+    if (rc == MCGP_OK) rc = ensure_ctx(device, &c);
+    if (rc != MCGP_OK) { delete kp; return rc; }
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto body = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        uint8_t *d_order = nullptr;
+        HIP_TRY(hipMalloc(&d_order, MCGP_MAX_CARS));
+        HIP_TRY(hipMemcpy(c->d_grid, grid, n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemsetAsync(c->d_hist, 0, sizeof(unsigned long long) * n * n, nullptr));
+        int r = launch(*c, *kp, 1, sim_id, seed, nullptr, c->d_hist, d_order, c->d_grid);
+        if (r == MCGP_OK) {
+            hipError_t e = hipMemcpy(order_out, d_order, n, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) r = fail(MCGP_E_HIP, std::string("hipMemcpy(order): ") + hipGetErrorString(e));
+        }
+        (void)hipFree(d_order);
+        return r;
+    };
+    rc = body();
+    delete kp;
+    return rc;
+}
+
+int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out)
+{
+    if (!ms_out) return fail(MCGP_E_BAD_ARG, "ms_out is NULL");
+    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready || !g_ctx[device].timed)
+        return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
+    DeviceCtx &c = g_ctx[device];
+    std::lock_guard<std::mutex> lock(c.mu);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipEventSynchronize(c.ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, c.ev_start, c.ev_stop));
+    return MCGP_OK;
+}
+
+int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads, uint32_t *lds_bytes)
+{
+    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready || !g_ctx[device].timed)
+        return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
+    if (grid_blocks) *grid_blocks = g_ctx[device].last_grid;
+    if (block_threads) *block_threads = g_ctx[device].last_block;
+    if (lds_bytes) *lds_bytes = g_ctx[device].last_lds;
+    return MCGP_OK;
+}
+
+}  // extern "C"

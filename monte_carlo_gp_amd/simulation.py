@@ -1,0 +1,257 @@
+"""Monte Carlo race simulation on MI355X -- host side of the drop-in boundary.
+
+Mirrors the reference's interface for the hot path (reference src/simulation.py):
+
+    RaceConfig                                   :37-52   same fields, same defaults
+    RaceSimulator(config)                        :55-57
+    RaceSimulator.run_monte_carlo(...)           :59-100  same arguments, same result shape
+    RaceSimulator.simulate_race(grid, ...)       :147-242 one race, list of (driver, position)
+
+The per-lap loop itself runs in hand-written HIP (csrc/race_kernel.hip.h) behind
+the C ABI of include/mcgp.h; this module only resolves the reference's dict
+defaults into dense arrays, calls the library through ctypes and reshapes the
+integer histogram into the reference's `dict[driver][position] -> probability`.
+There is no CPU path: without the HIP library or a GPU the calls raise.
+
+Randomness: the reference seeds two global Mersenne-Twister streams
+(:76-78); here every draw is a pure function of (seed, simulation id, lap,
+purpose, index) under Philox4x32-10, so results are reproducible for a given
+seed on any number of GPUs.  `seed=None` draws a 64-bit seed from Python's
+global `random`, which keeps a globally seeded backtest reproducible the way
+reference src/validation.py:172-174 relies on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class CarState:
+    """Per-car state of one simulation (reference :9-34); kept for interface parity.
+
+    On the device this is a structure-of-arrays row set in LDS, see csrc/race_kernel.hip.h.
+    """
+    driver: str
+    team: str
+    position: int
+    lap: int
+    tire_compound: str
+    tire_age: int
+    fuel_load: float
+    time_behind_leader: float
+    pit_stops: int
+    cumulative_time: float = 0.0
+    drs_enabled: bool = False
+    dnf: bool = False
+    used_compounds: set = field(default_factory=set)
+    laps_completed: int = 0
+    last_lap_time: float = 0.0
+
+    def __post_init__(self):
+        self.used_compounds.add(self.tire_compound)
+
+
+@dataclass
+class RaceConfig:
+    """Same fields and defaults as the reference's RaceConfig (:37-52)."""
+    total_laps: int
+    pit_loss: float
+    overtake_delta: float
+    sc_probability: float
+    vsc_probability: float
+    red_flag_probability: float
+    dnf_rates: dict
+    drs_zones: int
+    drs_delta: float
+    tire_compounds: dict
+    driver_teams: dict
+    dirty_air_threshold: float = 2.0
+    dirty_air_penalty: float = 0.5
+
+
+# `available.pop()` at reference :486,488 picks from a two-string set; CPython's answer
+# depends on PYTHONHASHSEED.  These are the outcomes under PYTHONHASHSEED=0 (the setting the
+# golden fixtures were made with, tests/golden/cases.json "set_pop").
+DEFAULT_SET_POP = {'SOFT_HARD': 'HARD', 'MEDIUM_HARD': 'MEDIUM'}
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class _Problem:
+    """run_monte_carlo's arguments resolved to the dense tables of include/mcgp.h."""
+
+    def __init__(self, config: RaceConfig, drivers, base_pace, tire_deg, driver_variance,
+                 driver_dnf_rates, track_condition, set_pop):
+        if track_condition not in N.TRACK_ID:
+            raise ValueError(f"track_condition must be 'dry', 'damp' or 'wet', got {track_condition!r}")
+        self.drivers = [str(d) for d in drivers]
+        n = self.n = len(self.drivers)
+        c = self.cfg = N.McgpConfig()
+        c.total_laps = int(config.total_laps)
+        c.track_condition = N.TRACK_ID[track_condition]
+        c.pit_loss = float(config.pit_loss)
+        c.overtake_delta = float(config.overtake_delta)
+        c.sc_probability = float(config.sc_probability)
+        c.vsc_probability = float(config.vsc_probability)
+        c.red_flag_probability = float(config.red_flag_probability)
+        c.drs_delta = float(config.drs_delta)
+        c.dirty_air_threshold = float(config.dirty_air_threshold)
+        c.dirty_air_penalty = float(config.dirty_air_penalty)
+        for name, i in N.COMPOUND_ID.items():
+            info = config.tire_compounds.get(name, {})        # reference :317,454
+            c.comp_pace_delta[i] = float(info.get('pace_delta', 0))
+            c.comp_deg_rate[i] = float(info.get('deg_rate', 0.05))
+            c.comp_optimal_laps[i] = int(info.get('optimal_laps', 30))
+        c.pop_soft_hard = N.COMPOUND_ID[set_pop['SOFT_HARD']]
+        c.pop_medium_hard = N.COMPOUND_ID[set_pop['MEDIUM_HARD']]
+
+        driver_dnf_rates = driver_dnf_rates or {}
+        team_rate = [config.dnf_rates.get(config.driver_teams.get(d, 'Unknown'), 0.002)   # :263,286
+                     for d in self.drivers]
+        f64 = np.float64
+        self.arrays = dict(
+            base_pace=np.array([base_pace.get(d, 90.0) for d in self.drivers], f64),           # :202
+            tire_deg=np.array([tire_deg.get(d, 0.05) for d in self.drivers], f64),             # :203
+            tire_deg_pit=np.array([tire_deg.get(d, 0.0) for d in self.drivers], f64),          # :458
+            variance=np.array([driver_variance.get(d, 0.15) for d in self.drivers], f64),      # :204
+            team_dnf=np.array(team_rate, f64),
+            lap_dnf=np.array([driver_dnf_rates.get(d, team_rate[i])                           # :190-193
+                              for i, d in enumerate(self.drivers)], f64),
+        )
+        self.drv = N.McgpDrivers(**{k: _dptr(v) for k, v in self.arrays.items()})
+
+
+class RaceSimulator:
+    """Drop-in for the reference's RaceSimulator (:55-560) with the race loop on the GPU."""
+
+    def __init__(self, config: RaceConfig, device: int = 0, set_pop: dict | None = None):
+        self.config = config
+        self.device = int(device)
+        self.set_pop = dict(set_pop or DEFAULT_SET_POP)
+        self.last_histogram = None      # np.int64 [n, n], counts[driver][position-1] of the last run
+        self.last_drivers = None
+        self._race_inputs = None
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _grid_matrix(grid_probs, drivers):
+        n = len(drivers)
+        g = np.zeros((n, n), np.float64)
+        for i, d in enumerate(drivers):
+            row = grid_probs[d]
+            m = min(len(row), n)             # `pos < len(grid_probs.get(d, []))` else 0, reference :120
+            g[i, :m] = np.asarray(row[:m], np.float64)
+        return np.ascontiguousarray(g)
+
+    @staticmethod
+    def _resolve_seed(seed):
+        if seed is None:
+            return random.getrandbits(64)
+        seed = int(seed)
+        if seed < 0:
+            seed = -seed                     # random.seed() uses abs(seed)
+        return seed & 0xFFFFFFFFFFFFFFFF
+
+    def _problem(self, drivers, base_pace, tire_deg, driver_variance, driver_dnf_rates, track_condition):
+        n = len(drivers)
+        if n < 1 or n > N.MAX_CARS:
+            raise ValueError(f'number of drivers must be in [1, {N.MAX_CARS}], got {n}')
+        return _Problem(self.config, drivers, base_pace, tire_deg, driver_variance, driver_dnf_rates,
+                        track_condition, self.set_pop)
+
+    # ------------------------------------------------------------------ reference surface
+    def run_monte_carlo(
+        self,
+        n_simulations: int,
+        grid_probs: dict,
+        base_pace: dict,
+        tire_deg: dict,
+        driver_variance: dict,
+        driver_dnf_rates: dict | None = None,
+        seed: int | None = None,
+        track_condition: str = 'dry',
+        sim_offset: int = 0,
+        return_orders: bool = False,
+    ):
+        """Run n simulations and return position probability distributions (reference :59-100).
+
+        Returns {driver: {position (1-based): probability}} holding only non-zero cells,
+        like the reference.  Extra keyword arguments (not in the reference):
+        sim_offset -- first global simulation id (for sharding a run over ranks);
+        return_orders -- also return the [n_sims, n] finishing orders (driver index per position).
+        """
+        drivers = [str(d) for d in grid_probs.keys()]
+        if not drivers or n_simulations <= 0:
+            self.last_histogram, self.last_drivers = np.zeros((len(drivers),) * 2, np.int64), drivers
+            return ({}, np.zeros((0, len(drivers)), np.uint8)) if return_orders else {}
+        prob = self._problem(drivers, base_pace, tire_deg, driver_variance, driver_dnf_rates, track_condition)
+        n = prob.n
+        g = self._grid_matrix({str(k): v for k, v in grid_probs.items()}, drivers)
+        hist = np.zeros((n, n), np.uint64)
+        orders = np.zeros((n_simulations, n), np.uint8) if return_orders else None
+        N.check(N.lib().mcgp_run(
+            C.byref(prob.cfg), C.byref(prob.drv), _dptr(g), n, int(n_simulations), int(sim_offset),
+            self._resolve_seed(seed), self.device, hist.ctypes.data_as(C.POINTER(C.c_uint64)),
+            orders.ctypes.data_as(C.POINTER(C.c_uint8)) if return_orders else None))
+        self.last_histogram = hist.astype(np.int64)
+        self.last_drivers = drivers
+        result = histogram_to_probs(self.last_histogram, drivers, n_simulations)
+        return (result, orders) if return_orders else result
+
+    def simulate_race(
+        self,
+        grid: list,
+        base_pace: dict,
+        tire_deg: dict,
+        driver_variance: dict,
+        driver_dnf_rates: dict | None = None,
+        track_condition: str = 'dry',
+        seed: int | None = None,
+        sim_id: int = 0,
+    ):
+        """Simulate a single race from a fixed grid; returns [(driver, position)] (reference :147-242)."""
+        drivers = [str(d) for d in grid]
+        if not drivers:
+            return []
+        prob = self._problem(drivers, base_pace, tire_deg, driver_variance, driver_dnf_rates, track_condition)
+        n = prob.n
+        g = np.arange(n, dtype=np.uint8)           # driver index == grid slot here
+        order = np.zeros(n, np.uint8)
+        N.check(N.lib().mcgp_simulate_race(
+            C.byref(prob.cfg), C.byref(prob.drv), g.ctypes.data_as(C.POINTER(C.c_uint8)), n, int(sim_id),
+            self._resolve_seed(seed), self.device, order.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return [(drivers[int(d)], p + 1) for p, d in enumerate(order)]
+
+    # ------------------------------------------------------------------ north-star alias
+    def set_race_inputs(self, base_pace=None, tire_deg=None, driver_variance=None, driver_dnf_rates=None,
+                        track_condition='dry'):
+        """Per-race inputs used by run_simulations(); missing dicts fall back to the reference defaults."""
+        self._race_inputs = dict(base_pace=base_pace or {}, tire_deg=tire_deg or {},
+                                 driver_variance=driver_variance or {}, driver_dnf_rates=driver_dnf_rates,
+                                 track_condition=track_condition)
+        return self
+
+    def run_simulations(self, grid: dict, n_sims: int, seed: int | None = None):
+        """run_simulations(grid, n_sims, seed): thin wrapper over run_monte_carlo (BASELINE north star)."""
+        ri = self._race_inputs or dict(base_pace={}, tire_deg={}, driver_variance={}, driver_dnf_rates=None,
+                                       track_condition='dry')
+        return self.run_monte_carlo(n_sims, grid, ri['base_pace'], ri['tire_deg'], ri['driver_variance'],
+                                    ri['driver_dnf_rates'], seed=seed, track_condition=ri['track_condition'])
+
+
+def histogram_to_probs(hist, drivers, n_simulations):
+    """counts[driver][position-1] -> {driver: {position: count / n}} with zero cells omitted (:97-100)."""
+    out = {}
+    for i, d in enumerate(drivers):
+        row = hist[i]
+        nz = np.nonzero(row)[0]
+        out[d] = {int(p) + 1: int(row[p]) / n_simulations for p in nz}
+    return out

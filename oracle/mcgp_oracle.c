@@ -6,7 +6,7 @@
  * cites the reference lines it follows.  The arithmetic is IEEE binary64 in
  * the reference's own evaluation order (compile with -ffp-contract=off).
  * Parity status: PINNED -- the MT back-end reproduces the reference's own
- * outputs (tests/golden/*.npz, produced by tests/golden/make_goldens.py from
+ * outputs (tests/golden/<case>.npz, produced by tests/golden/make_goldens.py from
  * the reference under PYTHONHASHSEED=0) bit for bit.
  */
 #include "mcgp_oracle.h"
@@ -231,11 +231,11 @@ float orc_normal_from_u32(uint32_t w)
 /*   counter = { sim_lo, sim_hi, lap, purpose << 16 | index }, key = seed      */
 /*   GRID  (lap 0)  index = slot >> 2, word = slot & 3                         */
 /*   EVENT (lap)    words: red flag, safety car, VSC, VSC tyre draw            */
-/*   CAR   (lap)    index = driver; words: DNF, lap noise,                     */
-/*                   lap 1: start delta / lap >= 2: overtake pass 0, pass 1     */
-/*   OVT2  (lap)    index = driver; word 0: overtake pass 2                    */
+/*   CAR   (lap)    index = driver; words: DNF, lap noise, start delta (lap 1) */
+/*   OVT   (lap)    the k-th overtake ATTEMPT of pass p (k counted along the   */
+/*                   pass's sorted order) reads word k & 3 of index 8p + k / 4  */
 /* ------------------------------------------------------------------------- */
-enum { PURPOSE_GRID = 0, PURPOSE_EVENT = 1, PURPOSE_CAR = 2, PURPOSE_OVT2 = 3 };
+enum { PURPOSE_GRID = 0, PURPOSE_EVENT = 1, PURPOSE_CAR = 2, PURPOSE_OVT = 3 };
 
 typedef struct {
     int mode;
@@ -269,11 +269,10 @@ static double draw_dnf(rng_t *r, int lap, int driver)
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :194,287 */
     return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver, 0));
 }
-static double draw_overtake(rng_t *r, int lap, int pass, int driver_behind)
+static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :524 */
-    if (pass < 2) return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver_behind, 2 + pass));
-    return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_OVT2, (uint32_t)driver_behind, 0));
+    return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_OVT, (uint32_t)(8 * pass + (attempt >> 2)), attempt & 3));
 }
 /* np.random.normal(0, scale) */
 static double draw_lap_noise(rng_t *r, int lap, int driver, double scale)
@@ -559,6 +558,7 @@ static void simulate_overtakes(const sim_t *s, car_t *cars, int lap)
     const orc_config *cfg = s->cfg;
     for (int pass = 0; pass < 3; pass++) {
         int overtake_occurred = 0;
+        int attempt = 0;
         int idx[MCGP_ORACLE_MAX_CARS];
         for (int i = 0; i < s->n; i++) idx[i] = i;           /* sorted(cars): DNF cars included (Q15) */
         stable_sort_by_time(cars, idx, s->n);
@@ -573,7 +573,7 @@ static void simulate_overtakes(const sim_t *s, car_t *cars, int lap)
             if (pace_delta > cfg->overtake_delta) {
                 double overtake_prob = pace_delta / 2.0;
                 if (!(overtake_prob < 0.5)) overtake_prob = 0.5;       /* min(0.5, x) */
-                if (draw_overtake(s->rng, lap, pass, behind->driver) < overtake_prob) {
+                if (draw_overtake(s->rng, lap, pass, attempt++) < overtake_prob) {
                     double new_behind_time = ahead->cumulative_time - 0.1;
                     if (!(new_behind_time > 0.1)) new_behind_time = 0.1;   /* max(0.1, x) */
                     behind->cumulative_time = new_behind_time;

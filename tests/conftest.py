@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def require_gpu():
+    """GPU tests must fail loudly (not skip) when the HIP path cannot run."""
+    from monte_carlo_gp_amd import _native
+    n = _native.lib().mcgp_device_count()
+    assert n > 0, 'no HIP device visible: the -m gpu tests need a GPU'
+    return n
