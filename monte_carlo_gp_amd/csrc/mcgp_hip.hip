@@ -8,6 +8,7 @@
 #include "../../include/mcgp.h"
 #include "normal_table.h"
 #include "race_kernel.hip.h"
+#include "race_kernel_reg.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -36,6 +37,9 @@ int fail(int code, const std::string &msg)
             return fail(e_ == hipErrorOutOfMemory ? MCGP_E_NOMEM : MCGP_E_HIP,                    \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                       \
     } while (0)
+
+// Field sizes with a register-resident instantiation; every other n runs the generic LDS kernel.
+#define MCGP_REG_SIZES(X) X(10) X(18) X(19) X(20) X(21) X(22)
 
 constexpr int kParamSlots = 4;
 
@@ -95,6 +99,11 @@ int ensure_ctx(int device, DeviceCtx **out)
         HIP_TRY(hipEventCreate(&c.ev_stop));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
+#define X(N_)                                                                                         \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel_reg<N_>),       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
+        MCGP_REG_SIZES(X)
+#undef X
         c.ready = true;
     }
     *out = &c;
@@ -175,15 +184,33 @@ int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
     return MCGP_OK;
 }
 
-// Launch geometry: as many waves per block as LDS allows (one block per CU),
-// persistent blocks striding over batches of blockDim.x simulations.
-void launch_geometry(const DeviceCtx &c, uint32_t n, uint64_t n_sims, uint32_t *grid, uint32_t *block,
+using KernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, uint32_t, unsigned long long *,
+                          uint8_t *, const uint8_t *, uint32_t);
+
+KernelFn select_kernel(uint32_t n, bool *is_reg)
+{
+    *is_reg = false;
+    const char *force = std::getenv("MCGP_FORCE_GENERIC");
+    if (force && force[0] == '1') return &mcgp::race_kernel;
+    switch (n) {
+#define X(N_) case N_: *is_reg = true; return &mcgp::race_kernel_reg<N_>;
+        MCGP_REG_SIZES(X)
+#undef X
+        default: return &mcgp::race_kernel;
+    }
+}
+
+// Launch geometry: persistent blocks striding over batches of blockDim.x simulations; as many
+// waves per CU as LDS allows.
+void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, uint64_t n_sims, uint32_t *grid, uint32_t *block,
                      uint32_t *lds)
 {
-    const size_t per_wave = 64 * mcgp::per_thread_lds_bytes((int)n);
+    const size_t per_thread = is_reg ? mcgp::per_thread_lds_bytes_reg((int)n) : mcgp::per_thread_lds_bytes((int)n);
+    const size_t per_wave = 64 * per_thread;
     int waves = (int)((c.lds_per_block - mcgp::kSharedTableBytes) / per_wave);
     if (waves > 8) waves = 8;
     if (waves < 1) waves = 1;
+    if (is_reg && waves > 4) waves = 4;        // __launch_bounds__(256): two such blocks share a CU
     int blocks_per_cu = 1;
     if (const char *e = std::getenv("MCGP_WAVES_PER_BLOCK")) {
         const int w = std::atoi(e);
@@ -204,7 +231,7 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, uint64_t n_sims, uint32_t *
     if (g < 1) g = 1;
     *grid = (uint32_t)g;
     *block = threads;
-    *lds = (uint32_t)(mcgp::kSharedTableBytes + (size_t)threads * mcgp::per_thread_lds_bytes((int)n));
+    *lds = (uint32_t)(mcgp::kSharedTableBytes + (size_t)threads * per_thread);
 }
 
 int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
@@ -212,7 +239,9 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
 {
     if (n_sims == 0) return MCGP_OK;
     uint32_t grid, block, lds;
-    launch_geometry(c, (uint32_t)kp.n, n_sims, &grid, &block, &lds);
+    bool is_reg = false;
+    const KernelFn kernel = select_kernel((uint32_t)kp.n, &is_reg);
+    launch_geometry(c, (uint32_t)kp.n, is_reg, n_sims, &grid, &block, &lds);
     const uint64_t n_batches = (n_sims + block - 1) / block;
     if (n_batches > 0xffffffffull) return fail(MCGP_E_BAD_ARG, "n_sims too large for one launch");
     DeviceCtx::Slot *sl = nullptr;
@@ -227,7 +256,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, sizeof(kp), hipMemcpyHostToDevice, stream));
     }
     HIP_TRY(hipEventRecord(c.ev_start, stream));
-    hipLaunchKernelGGL(mcgp::race_kernel, dim3(grid), dim3(block), lds, stream, sl->dev, n_sims,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, n_sims,
                        sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32), d_hist, d_orders, d_fixed_grid,
                        (uint32_t)n_batches);
     HIP_TRY(hipGetLastError());

@@ -404,7 +404,8 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                     const double ahead_last = carry;
                     carry = s.Last(d);
                     uint32_t w0, w1, w2, w3;
-                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | d, seed_lo, seed_hi, w0, w1, w2, w3);
+                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (d >> 1), seed_lo, seed_hi, w0, w1, w2, w3);
+                    if (d & 1u) { w0 = w2; w1 = w3; }               // one block serves drivers 2j and 2j+1
                     if ((uint64_t)w0 < t_dnf[d]) {                  // :194-197
                         s.Pk(d) = (pk & ~kAgeMask) | kDnf | (uint32_t)lap;
                         continue;
@@ -472,7 +473,7 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
                 for (uint32_t k = 0; cand != 0u; ++k) {
                     if ((k & 3u) == 0u)
-                        philox4x32_10(c0, c1, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass) + (k >> 2),
+                        philox4x32_10(c0, c1, (uint32_t)lap, kPurposeOvt | ((uint32_t)(8 * pass) + (k >> 2)),
                                       seed_lo, seed_hi, o0, o1, o2, o3);
                     const uint32_t ow = (k & 3u) == 0u ? o0 : (k & 3u) == 1u ? o1 : (k & 3u) == 2u ? o2 : o3;
                     const int i = __ffs((int)cand) - 1;

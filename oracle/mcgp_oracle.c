@@ -231,7 +231,9 @@ float orc_normal_from_u32(uint32_t w)
 /*   counter = { sim_lo, sim_hi, lap, purpose << 16 | index }, key = seed      */
 /*   GRID  (lap 0)  index = slot >> 2, word = slot & 3                         */
 /*   EVENT (lap)    words: red flag, safety car, VSC, VSC tyre draw            */
-/*   CAR   (lap)    index = driver; words: DNF, lap noise, start delta (lap 1) */
+/*   CAR   (lap 1)  index = driver; words: DNF, lap noise, start delta          */
+/*   CAR   (lap>=2) index = driver >> 1 (one block serves two drivers);        */
+/*                   words 2 (driver & 1) + {0: DNF, 1: lap noise}              */
 /*   OVT   (lap)    the k-th overtake ATTEMPT of pass p (k counted along the   */
 /*                   pass's sorted order) reads word k & 3 of index 8p + k / 4  */
 /* ------------------------------------------------------------------------- */
@@ -267,7 +269,8 @@ static double draw_event(rng_t *r, int lap, int which)
 static double draw_dnf(rng_t *r, int lap, int driver)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :194,287 */
-    return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver, 0));
+    if (lap == 1) return u32_to_unit(philox_word(r, 1u, PURPOSE_CAR, (uint32_t)driver, 0));
+    return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1)));
 }
 static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
 {
@@ -278,7 +281,9 @@ static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
 static double draw_lap_noise(rng_t *r, int lap, int driver, double scale)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return orc_mt_np_normal(r->mt, 0.0, scale);   /* :330 */
-    return 0.0 + scale * (double)orc_normal_from_u32(philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver, 1));
+    const uint32_t w = lap == 1 ? philox_word(r, 1u, PURPOSE_CAR, (uint32_t)driver, 1)
+                                : philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1) + 1);
+    return 0.0 + scale * (double)orc_normal_from_u32(w);
 }
 static double draw_start_delta(rng_t *r, int driver, double scale)
 {
