@@ -76,33 +76,55 @@ __device__ __forceinline__ bool cmpx(double &ca, uint32_t &pa, double &cb, uint3
     return sw;
 }
 
+// compare-exchange on the time alone (ties left as they are): the network's comparator.
+__device__ __forceinline__ void cmpx_time(double &ca, uint32_t &pa, double &cb, uint32_t &pb)
+{
+    const bool sw = ca > cb;
+    const double c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+    const uint32_t p0 = sw ? pb : pa, p1 = sw ? pa : pb;
+    ca = c0; cb = c1; pa = p0; pb = p1;
+}
+
 template <int N, size_t... I>
 __device__ __forceinline__ void network_sort_impl(double (&cum)[N], uint32_t (&pk)[N], std::index_sequence<I...>)
 {
     constexpr MergeExchange<N> net{};
-    ((void)cmpx(cum[net.a[I]], pk[net.a[I]], cum[net.b[I]], pk[net.b[I]]), ...);
+    (cmpx_time(cum[net.a[I]], pk[net.a[I]], cum[net.b[I]], pk[net.b[I]]), ...);
+}
+
+// Is the field in (cumulative_time, grid slot) order?
+template <int N>
+__device__ __forceinline__ bool in_order(const double (&cum)[N], const uint32_t (&pk)[N])
+{
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i + 1 < N; ++i)
+        bad |= (cum[i] > cum[i + 1]) || (cum[i] == cum[i + 1] && pk[i] > pk[i + 1]);
+    return !bad;
+}
+
+// Odd-even transposition rounds until the field is in order: the re-sort after a LOCAL
+// perturbation (an overtake pass moves a few cars by 0.1-0.3 s).
+template <int N>
+__device__ __forceinline__ void transposition_sort(double (&cum)[N], uint32_t (&pk)[N])
+{
+    do {
+#pragma unroll
+        for (int i = 0; i + 1 < N; i += 2) (void)cmpx(cum[i], pk[i], cum[i + 1], pk[i + 1]);
+#pragma unroll
+        for (int i = 1; i + 1 < N; i += 2) (void)cmpx(cum[i], pk[i], cum[i + 1], pk[i + 1]);
+    } while (!in_order<N>(cum, pk));
 }
 
 // Full sort by (cumulative_time, grid slot): Python's stable sorted() of the reference (:506 etc.).
+// The network orders by time; equal times (structural: lap-1 retirements at 0.0) are then put in
+// grid order by the transposition rounds, which almost never have anything to do.
 template <int N>
 __device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N])
 {
     constexpr MergeExchange<N> net{};
     network_sort_impl<N>(cum, pk, std::make_index_sequence<(size_t)net.n>{});
-}
-
-// Re-sort after a local perturbation: odd-even transposition rounds until a round swaps nothing.
-template <int N>
-__device__ __forceinline__ void transposition_sort(double (&cum)[N], uint32_t (&pk)[N])
-{
-    bool any;
-    do {
-        any = false;
-#pragma unroll
-        for (int i = 0; i + 1 < N; i += 2) any |= cmpx(cum[i], pk[i], cum[i + 1], pk[i + 1]);
-#pragma unroll
-        for (int i = 1; i + 1 < N; i += 2) any |= cmpx(cum[i], pk[i], cum[i + 1], pk[i + 1]);
-    } while (any);
+    if (!in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
 }
 
 // _update_positions, reference :538-560.
@@ -315,7 +337,8 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     const bool dec_age = sc || (vsc && (uint64_t)e3 < P->t_vsc_tire);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     int k = 0;
-                    double leader = 0.0;
+                    double leader = 0.0, prev_nt = -1.0;
+                    bool tie = false;
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
                         uint32_t p = pk[i];
@@ -326,6 +349,8 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                             if (red) nt = leader + (double)k * 0.1;
                             else if (sc) nt = leader + (double)k * 0.5;
                             else { const double gap = t - leader; nt = leader + gap * 0.8; }
+                            tie |= nt == prev_nt;
+                            prev_nt = nt;
                             const double tbl = nt - leader;
                             p &= ~k2Dirty;
                             if (tbl > 0 && tbl < dirty_thr) p |= k2Dirty;
@@ -342,10 +367,10 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                         }
                     }
                     drs_disabled_until = lap + (vsc ? 1 : 2);
-                    // SC / red flag keep the running cars' relative order strictly (the only order the lap
-                    // loop below needs; the full order is rebuilt after it).  x0.8 is monotone but may round
-                    // two gaps together, and equal times must fall back to grid order.
-                    if (vsc) transposition_sort<N>(cum, pk);
+                    // Re-spacing keeps the running cars' relative order (the only order the lap loop below
+                    // needs; the full order is rebuilt after it).  x0.8 is monotone but may round two gaps
+                    // together, and equal times must fall back to grid order: re-sort only then.
+                    if (tie) transposition_sort<N>(cum, pk);
                 }
             }
 

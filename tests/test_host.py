@@ -1,0 +1,121 @@
+"""Host-side logic and the C-ABI surface; no GPU needed (no compute entry point is called
+successfully here: without a device they must fail loudly)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N, histogram_to_probs
+from monte_carlo_gp_amd import config as K
+from monte_carlo_gp_amd.simulation import _Problem, DEFAULT_SET_POP
+
+
+def test_library_exports_every_declared_symbol():
+    L = N.lib()
+    with open(O.ROOT + '/include/mcgp.h') as f:
+        header = f.read()
+    declared = set(re.findall(r'\b(mcgp_[a-z_]+)\s*\(', header))
+    assert declared == set(N.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.mcgp_abi_version() == 1
+    assert L.mcgp_device_count() >= 0
+
+
+def test_struct_layout_matches_header():
+    # 2 x int32, 8 x double, 5 + 5 double, 5 int32, 2 int32
+    assert C.sizeof(N.McgpConfig) == 8 + 8 * 8 + 10 * 8 + 5 * 4 + 2 * 4 + 4  # trailing pad to 8
+    assert C.sizeof(N.McgpDrivers) == 6 * C.sizeof(C.c_void_p)
+    assert C.sizeof(O.OrcConfig) == C.sizeof(N.McgpConfig)
+
+
+def test_constants_match_reference_tables():
+    import json
+    with open(O.GOLDEN_DIR + '/misc.json') as f:
+        m = json.load(f)
+    assert K.DRIVER_TEAMS == m['driver_teams'] and list(K.DRIVER_TEAMS) == list(m['driver_teams'])
+    assert K.DEFAULT_DNF_RATES == m['dnf_rates']
+    assert K.TIRE_COMPOUNDS == m['tire_compounds']
+    assert K.CIRCUITS == m['circuits'] and list(K.CIRCUITS) == list(m['circuits'])
+    assert m['race_config_bahrain'] == [57, 21.0, 0.6, K.SC_PROBABILITY, K.VSC_PROBABILITY,
+                                        K.RED_FLAG_PROBABILITY, K.DRS_DELTA]
+
+
+def test_default_set_pop_is_the_hashseed0_outcome():
+    assert DEFAULT_SET_POP == {k: v for k, v in O.load_cases()['set_pop'].items() if k in DEFAULT_SET_POP}
+
+
+def test_problem_resolution_applies_reference_defaults():
+    case = O.load_case('HET')          # has missing dict entries and an unknown driver
+    cfg = RaceConfig(**case['config'])
+    drivers = list(case['grid_probs'])
+    p = _Problem(cfg, drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
+                 case['driver_dnf_rates'], 'dry', DEFAULT_SET_POP)
+    ref = O.Problem(case)
+    for k in ref.arr:
+        assert np.array_equal(p.arrays[k], ref.arr[k]), k
+    i = drivers.index('XXX')
+    assert p.arrays['team_dnf'][i] == 0.002 and p.arrays['tire_deg'][i] == 0.05 and p.arrays['tire_deg_pit'][i] == 0.0
+    assert p.arrays['base_pace'][drivers.index('HUL')] == 90.0
+    assert p.arrays['variance'][drivers.index('OCO')] == 0.15
+    j = drivers.index('VER')
+    assert p.arrays['lap_dnf'][j] == p.arrays['team_dnf'][j]
+    assert bytes(p.cfg) == bytes(ref.cfg)
+
+
+def test_histogram_to_probs_shape():
+    h = np.array([[3, 0, 1], [1, 3, 0], [0, 1, 3]])
+    out = histogram_to_probs(h, ['A', 'B', 'C'], 4)
+    assert out == {'A': {1: 0.75, 3: 0.25}, 'B': {1: 0.25, 2: 0.75}, 'C': {2: 0.25, 3: 0.75}}
+
+
+def test_argument_validation_and_loud_failure_without_device():
+    sim = RaceSimulator(RaceConfig(10, 20.0, 0.5, 0.01, 0.01, 0.001, {}, 2, 0.3, K.TIRE_COMPOUNDS, {}))
+    assert sim.run_monte_carlo(0, {'A': [1.0]}, {}, {}, {}) == {}
+    assert sim.run_monte_carlo(10, {}, {}, {}, {}) == {}
+    with pytest.raises(ValueError):
+        sim.run_monte_carlo(10, {str(i): [1 / 33] * 33 for i in range(33)}, {}, {}, {}, seed=1)
+    with pytest.raises(ValueError):
+        sim.run_monte_carlo(10, {'A': [1.0]}, {}, {}, {}, seed=1, track_condition='snow')
+    if N.lib().mcgp_device_count() == 0:
+        with pytest.raises(N.McgpError) as e:
+            sim.run_monte_carlo(10, {'A': [0.5, 0.5], 'B': [0.5, 0.5]}, {}, {}, {}, seed=1)
+        assert e.value.code == -2 and 'no HIP device' in str(e.value)
+
+
+def test_c_abi_rejects_bad_arguments():
+    L = N.lib()
+    case = O.load_case('N10')
+    p = _Problem(RaceConfig(**case['config']), list(case['grid_probs']), case['base_pace'], case['tire_deg'],
+                 case['driver_variance'], case['driver_dnf_rates'], 'dry', DEFAULT_SET_POP)
+    g = np.full((10, 10), 0.1)
+    h = np.zeros(100, np.uint64)
+    gp, hp = g.ctypes.data_as(C.POINTER(C.c_double)), h.ctypes.data_as(C.POINTER(C.c_uint64))
+    assert L.mcgp_run(None, C.byref(p.drv), gp, 10, 5, 0, 1, 0, hp, None) == -1
+    assert L.mcgp_run(C.byref(p.cfg), C.byref(p.drv), gp, 0, 5, 0, 1, 0, hp, None) == -1
+    assert L.mcgp_run(C.byref(p.cfg), C.byref(p.drv), gp, 33, 5, 0, 1, 0, hp, None) == -1
+    assert L.mcgp_run(C.byref(p.cfg), C.byref(p.drv), None, 10, 5, 0, 1, 0, hp, None) == -1
+    assert b'NULL' in L.mcgp_last_error()
+    bad = N.McgpConfig.from_buffer_copy(bytes(p.cfg))
+    bad.total_laps = 5000
+    assert L.mcgp_run(C.byref(bad), C.byref(p.drv), gp, 10, 5, 0, 1, 0, hp, None) == -1
+    g[3, 4] = -0.5
+    assert L.mcgp_run(C.byref(p.cfg), C.byref(p.drv), gp, 10, 5, 0, 1, 0, hp, None) == -1
+    grid = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 8], np.uint8)    # not a permutation
+    o = np.zeros(10, np.uint8)
+    assert L.mcgp_simulate_race(C.byref(p.cfg), C.byref(p.drv), grid.ctypes.data_as(C.POINTER(C.c_uint8)), 10, 0, 1,
+                                0, o.ctypes.data_as(C.POINTER(C.c_uint8))) == -1
+    assert h.sum() == 0
+
+
+def test_seed_resolution():
+    import random
+    assert RaceSimulator._resolve_seed(42) == 42
+    assert RaceSimulator._resolve_seed(-42) == 42
+    assert RaceSimulator._resolve_seed(2 ** 70 + 5) == 5
+    random.seed(123)
+    a = RaceSimulator._resolve_seed(None)
+    random.seed(123)
+    assert RaceSimulator._resolve_seed(None) == a       # a globally seeded run stays reproducible (Q20)
