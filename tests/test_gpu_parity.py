@@ -28,3 +28,94 @@ def test_orders_and_histogram_match_oracle(require_gpu, name):
     for i, d in enumerate(P.drivers):
         assert set(probs[d].keys()) == {int(p) + 1 for p in np.nonzero(ref['hist'][i])[0]}
     assert abs(sum(sum(v.values()) for v in probs.values()) - P.n) < 1e-9
+
+
+def test_partition_and_offset_invariance(require_gpu):
+    """Any split of [0, N) over calls gives the same orders / histogram; 64-bit ids and seeds."""
+    case = O.load_case('S50')
+    seed = 0xDEADBEEFCAFEF00D
+    base = (1 << 40) + 12345
+    hist, _, orders = product_run(case, 1500, seed, sim_offset=base, orders=True)
+    h1, _, o1 = product_run(case, 333, seed, sim_offset=base, orders=True)
+    h2, _, o2 = product_run(case, 1167, seed, sim_offset=base + 333, orders=True)
+    assert np.array_equal(np.vstack([o1, o2]), orders)
+    assert np.array_equal(h1 + h2, hist)
+    ref = O.Problem(case).run(1500, rng=O.RNG_PHILOX, seed=seed, sim_offset=base, want_orders=True)
+    assert np.array_equal(orders, ref['orders'])
+
+
+def test_generic_and_register_kernels_agree(require_gpu, monkeypatch):
+    """n = 20 has a register-resident instantiation; MCGP_FORCE_GENERIC routes the same problem to the LDS kernel."""
+    case = O.load_case('EVT')
+    a = product_run(case, 2000, 9, orders=True)
+    monkeypatch.setenv('MCGP_FORCE_GENERIC', '1')
+    b = product_run(case, 2000, 9, orders=True)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 23, 32])
+def test_field_sizes_without_register_instantiation(require_gpu, n):
+    """Generic kernel, every field size up to the ABI maximum, ragged/zero grid columns (Q18 fallback)."""
+    rng = np.random.default_rng(n)
+    drivers = [f'D{i:02d}' for i in range(n)]
+    base = O.load_case('S60')
+    case = dict(base)
+    case['config'] = dict(base['config'], total_laps=25,
+                          driver_teams={d: list(base['config']['dnf_rates'])[i % 10] for i, d in enumerate(drivers)})
+    g = rng.random((n, n))
+    g[:, n // 2] = 0.0                      # an all-zero column: uniform-over-remaining fallback
+    case['grid_probs'] = {d: [float(x) for x in g[i]] for i, d in enumerate(drivers)}
+    case['base_pace'] = {d: 90.0 + 0.2 * i for i, d in enumerate(drivers)}
+    case['tire_deg'] = {d: 0.05 for d in drivers}
+    case['driver_variance'] = {d: 0.2 for d in drivers}
+    case['driver_dnf_rates'] = {d: 0.01 for d in drivers}
+    hist, probs, orders = product_run(case, 1000, 5, orders=True)
+    ref = O.Problem(case).run(1000, rng=O.RNG_PHILOX, seed=5, want_orders=True)
+    assert np.array_equal(orders, ref['orders'])
+    assert np.array_equal(hist, ref['hist'])
+
+
+def test_simulate_race_matches_oracle_and_run(require_gpu):
+    case = O.load_case('HET')
+    sim = product_sim(case)
+    P = O.Problem(case)
+    rng = np.random.default_rng(0)
+    for sim_id in (0, 5, 1 << 33):
+        perm = rng.permutation(P.n)
+        grid = [P.drivers[i] for i in perm]
+        # the product API takes the grid as a driver list; dict inputs are keyed by driver
+        res = sim.simulate_race(grid, case['base_pace'], case['tire_deg'], case['driver_variance'],
+                                case['driver_dnf_rates'], case['track_condition'], seed=77, sim_id=sim_id)
+        assert [p for _, p in res] == list(range(1, P.n + 1))
+        # oracle problem with drivers re-indexed in grid order (driver index == grid slot)
+        sub = dict(case, grid_probs={d: case['grid_probs'][d] for d in grid})
+        order = O.Problem(sub).simulate_race(np.arange(P.n), rng=O.RNG_PHILOX, seed=77, sim_id=sim_id)
+        assert [d for d, _ in res] == [grid[int(i)] for i in order]
+
+
+def test_tail_batches_and_tiny_runs(require_gpu):
+    case = O.load_case('N10')
+    P = O.Problem(case)
+    for n_sims in (1, 63, 64, 65, 257, 1025):
+        hist, _, orders = product_run(case, n_sims, 3, orders=True)
+        ref = P.run(n_sims, rng=O.RNG_PHILOX, seed=3, want_orders=True)
+        assert np.array_equal(orders, ref['orders']), n_sims
+        assert np.array_equal(hist, ref['hist']), n_sims
+
+
+def test_histogram_accumulates_and_orders_optional(require_gpu):
+    import ctypes as C
+    from monte_carlo_gp_amd import _native as N
+    from monte_carlo_gp_amd.simulation import _Problem, _dptr, RaceSimulator
+    from monte_carlo_gp_amd import RaceConfig
+    case = O.load_case('WET')
+    drivers = list(case['grid_probs'])
+    p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'],
+                 case['driver_variance'], case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
+    g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+    h = np.zeros((p.n, p.n), np.uint64)
+    for off in (0, 500):
+        N.check(N.lib().mcgp_run(C.byref(p.cfg), C.byref(p.drv), _dptr(g), p.n, 500, off, 21, 0,
+                                 h.ctypes.data_as(C.POINTER(C.c_uint64)), None))
+    ref = O.Problem(case).run(1000, rng=O.RNG_PHILOX, seed=21)
+    assert np.array_equal(h.astype(np.int64), ref['hist'])
