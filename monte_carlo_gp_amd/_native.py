@@ -65,8 +65,11 @@ def lib():
     """Load the library (building it if the sources are newer); raises if impossible."""
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(LIB_PATH)
+        path = os.environ.get('MCGP_LIB')          # diagnostic builds (tools/ablate.sh)
+        if not path:
+            build()
+            path = LIB_PATH
+        L = C.CDLL(path)
         L.mcgp_abi_version.restype = C.c_int32
         L.mcgp_device_count.restype = C.c_int32
         L.mcgp_last_error.restype = C.c_char_p

@@ -26,6 +26,12 @@
 #pragma once
 #include "race_kernel.hip.h"
 
+// Diagnostic builds only (tools/ablate.sh): bit k set = run section k twice (each section is
+// idempotent, results unchanged) so its cost shows up as a time difference.  0 in the product build.
+#ifndef MCGP_DUP
+#define MCGP_DUP 0
+#endif
+
 #include <utility>
 
 namespace mcgp {
@@ -66,11 +72,22 @@ struct MergeExchange {
     }
 };
 
+// v_min_f64 / v_max_f64 issued directly: through fmin()/fmax() hipcc adds a canonicalising
+// v_max_f64 x, x, x per operand (IEEE mode quiets signalling NaNs), tripling the cost.  Times are
+// finite and non-negative here, for which the bare instructions are exact.  Plain VALU, interlocked
+// by hardware: no wait states needed inside the statement.
+__device__ __forceinline__ void minmax_f64(double a, double b, double &lo, double &hi)
+{
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+}
+
 // compare-exchange on (cum, pk): after it, slot A sorts before slot B.
 __device__ __forceinline__ bool cmpx(double &ca, uint32_t &pa, double &cb, uint32_t &pb)
 {
     const bool sw = (ca > cb) || (ca == cb && pa > pb);
-    const double c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+    double c0, c1;
+    minmax_f64(ca, cb, c0, c1);
     const uint32_t p0 = sw ? pb : pa, p1 = sw ? pa : pb;
     ca = c0; cb = c1; pa = p0; pb = p1;
     return sw;
@@ -80,7 +97,8 @@ __device__ __forceinline__ bool cmpx(double &ca, uint32_t &pa, double &cb, uint3
 __device__ __forceinline__ void cmpx_time(double &ca, uint32_t &pa, double &cb, uint32_t &pb)
 {
     const bool sw = ca > cb;
-    const double c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+    double c0, c1;
+    minmax_f64(ca, cb, c0, c1);
     const uint32_t p0 = sw ? pb : pa, p1 = sw ? pa : pb;
     ca = c0; cb = c1; pa = p0; pb = p1;
 }
@@ -330,6 +348,11 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             {
                 uint32_t e0, e1, e2, e3;
                 philox4x32_10(c0, c1, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, e0, e1, e2, e3);
+                if (MCGP_DUP & 16) {
+                    uint32_t f0, f1, f2, f3;
+                    philox4x32_10(c0 ^ e0, c1, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, f0, f1, f2, f3);
+                    if ((f0 | f1 | f2 | f3) == 0u) e0 = f0;     // never true in practice; keeps the block alive
+                }
                 const bool red = (uint64_t)e0 < P->t_red;
                 const bool sc = !red && (uint64_t)e1 < P->t_sc;
                 const bool vsc = !red && !sc && (uint64_t)e2 < P->t_vsc;
@@ -375,6 +398,8 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             }
 
             // ---- this lap's draws, by driver pair: one Philox block = (dnf, noise) x 2 ----
+#pragma unroll 1
+            for (int rep = 0; rep < ((MCGP_DUP & 2) ? 2 : 1); ++rep)
 #pragma unroll 1
             for (int b = 0; b < (N + 1) / 2; ++b) {
                 uint32_t w0, w1, w2, w3;
@@ -439,6 +464,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
 
             // ---- _simulate_overtakes, :496-536 ----
             network_sort<N>(cum, pk);
+            if (MCGP_DUP & 1) network_sort<N>(cum, pk);
 #pragma unroll 1
             for (int pass = 0; pass < 3; ++pass) {
                 double pace[N];
@@ -488,8 +514,10 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                 }
                 if (!success) break;
                 transposition_sort<N>(cum, pk);     // sorted again for the next pass / _update_positions
+                if (MCGP_DUP & 8) transposition_sort<N>(cum, pk);
             }
             update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);   // :227-228
+            if (MCGP_DUP & 4) update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
         }
 
         // ================= classification, reference :230-242 =================
