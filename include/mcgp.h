@@ -126,6 +126,7 @@ int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, cons
 int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out);
 int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads,
                               uint32_t *lds_bytes);
+const char *mcgp_last_kernel_name(int32_t device);   /* "" before the first launch */
 
 #ifdef __cplusplus
 }

@@ -58,7 +58,7 @@ def build(force=False):
 _lib = None
 
 EXPORTS = ('mcgp_abi_version', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
-           'mcgp_simulate_race', 'mcgp_last_kernel_ms', 'mcgp_last_launch_info')
+           'mcgp_simulate_race', 'mcgp_last_kernel_ms', 'mcgp_last_launch_info', 'mcgp_last_kernel_name')
 
 
 def lib():
@@ -85,6 +85,8 @@ def lib():
                                          C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint8)]
         L.mcgp_last_kernel_ms.restype = C.c_int32
         L.mcgp_last_kernel_ms.argtypes = [C.c_int32, C.POINTER(C.c_float)]
+        L.mcgp_last_kernel_name.restype = C.c_char_p
+        L.mcgp_last_kernel_name.argtypes = [C.c_int32]
         L.mcgp_last_launch_info.restype = C.c_int32
         L.mcgp_last_launch_info.argtypes = [C.c_int32] + [C.POINTER(C.c_uint32)] * 3
         if L.mcgp_abi_version() != ABI_VERSION:

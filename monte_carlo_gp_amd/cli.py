@@ -1,0 +1,182 @@
+"""Command line: the reference's main.py / backtest.py flags, working offline.
+
+    python -m monte_carlo_gp_amd.cli predict  --race Bahrain --season 2024 --simulations 10000 --seed 42 --offline
+    python -m monte_carlo_gp_amd.cli backtest --seasons 2024 --seed 42 --simulations 10000000
+
+Flags kept from the reference: --season, --race, --prediction-point, --simulations (main.py:8-16);
+--seasons, --seed (backtest.py:9-14).  Unlike the reference, --simulations and --seed reach the
+simulator (the reference parses --simulations and drops it, main.py:14-15 vs predictor.py:284).
+--offline / --fixture replace the FastF1 sessions with a race fixture (see predictor.py); without
+--fixture a synthetic weekend is used (SURVEY.md 8d canonical inputs) and labelled as such.
+Under torch.distributed.run the backtest shards RACES over ranks (independent problems, no collective
+on the data path; results are gathered once).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+from . import config as K
+from .predictor import F1Predictor, circuit_info
+from .validation import brier_score, podium_accuracy
+
+
+def synthetic_fixture(drivers=None) -> dict:
+    """Canonical synthetic weekend: Elo 1700 - 20 i, pace 90 + 0.1 i, deg 0.05, empty features."""
+    drivers = list(drivers or K.DRIVER_TEAMS)
+    return dict(
+        drivers=drivers,
+        quali_ratings={d: 1700.0 - 20.0 * i for i, d in enumerate(drivers)},
+        quali_features={}, race_features={},
+        practice=dict(base_pace={d: 90.0 + 0.1 * i for i, d in enumerate(drivers)},
+                      tire_deg={d: 0.05 for d in drivers}, tire_compounds=None),
+        weather={'rainfall': False},
+        synthetic=True,
+    )
+
+
+def _bars(title, probs, top=10):
+    print(title)
+    print('-' * 40)
+    for i, (d, p) in enumerate(sorted(probs.items(), key=lambda kv: kv[1], reverse=True)[:top], 1):
+        print(f"{i:2}. {d:4} {p:6.1%} {'#' * int(p * 30)}")
+
+
+def cmd_predict(args) -> int:
+    fixture = synthetic_fixture()
+    if args.fixture:
+        with open(args.fixture) as f:
+            fixture = json.load(f)
+    elif not args.offline:
+        print('error: live FastF1 data is not available in this build; use --offline or --fixture FILE', file=sys.stderr)
+        return 2
+    print(f"\n{'=' * 60}\nF1 Race Prediction: {args.season} {args.race}\nPrediction point: {args.prediction_point}")
+    print(f"Simulations: {args.simulations}  seed: {args.seed}  data: "
+          f"{'synthetic fixture' if fixture.get('synthetic') else args.fixture}\n{'=' * 60}\n")
+    t0 = time.perf_counter()
+    res = F1Predictor(device=args.device).predict_weekend(
+        args.season, args.race, fixture, prediction_point=args.prediction_point,
+        n_simulations=args.simulations, seed=args.seed)
+    dt = time.perf_counter() - t0
+    print(f"Weather: {'Wet' if res['weather'].get('rainfall') else 'Dry'}")
+    print(f"Confidence: {res['confidence']}   ({args.simulations / dt:,.0f} simulations/s incl. setup)\n")
+    _bars('POLE POSITION PROBABILITIES', res['pole_probabilities'])
+    print()
+    _bars('RACE WINNER PROBABILITIES', res['win_probabilities'])
+    print()
+    _bars('PODIUM PROBABILITIES', res['podium_probabilities'])
+    if args.json:
+        with open(args.json, 'w') as f:
+            json.dump({k: v for k, v in res.items() if k != 'full_distributions'}, f)
+    return 0
+
+
+def load_results(season: int) -> list:
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', f'results_{season}.json')
+    with open(path) as f:
+        return json.load(f)['races']
+
+
+def backtest_jobs(seasons, seed):
+    """(season, result entry, per-race seed) for every race of the sweep, in calendar order."""
+    rng = random.Random(seed)
+    return [(season, entry, rng.getrandbits(63)) for season in seasons for entry in load_results(season)]
+
+
+def shard_jobs(jobs, rank, world):
+    """Round-robin share of the races for one rank: [(global index, job)]."""
+    return [(i, j) for i, j in enumerate(jobs) if i % world == rank]
+
+
+def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, predictor_factory=None):
+    """Sweep one prediction per race of each season and score it (reference validation.py:161-209).
+
+    Each race gets its own seed drawn from random.Random(seed) (the reference seeds the global
+    streams once and lets them run on, :172-174; per-race seeds keep races independent so they can
+    shard over GPUs).  Returns the reference's result dict plus per-race rows.
+    """
+    mine = shard_jobs(backtest_jobs(seasons, seed), rank, world)
+    predictor = (predictor_factory or (lambda: F1Predictor(device=device)))()
+    rows = []
+    for i, (season, entry, race_seed) in mine:
+        res = predictor.predict_weekend(season, entry['race'], synthetic_fixture(), n_simulations=n_simulations,
+                                        seed=race_seed)
+        rows.append((i, dict(race=entry['race'], season=season, laps=circuit_info(entry['race'])['laps'],
+                             pole=res['pole_probabilities'], win=res['win_probabilities'],
+                             podium_probabilities=res['podium_probabilities'], actual=entry)))
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        rows = [r for part in gathered for r in part]
+    rows = [r for _, r in sorted(rows, key=lambda t: t[0])]
+    preds = [dict(pole_probabilities=r['pole'], win_probabilities=r['win'],
+                  podium_probabilities=r['podium_probabilities']) for r in rows]
+    acts = [r['actual'] for r in rows]
+    return {
+        'pole_brier': float(brier_score([p['pole_probabilities'] for p in preds], [a['pole'] for a in acts])),
+        'win_brier': float(brier_score([p['win_probabilities'] for p in preds], [a['winner'] for a in acts])),
+        'podium_accuracy': podium_accuracy(preds, acts),
+        'n_races': len(rows),
+        'races': rows,
+    }
+
+
+def cmd_backtest(args) -> int:
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    device = int(os.environ.get('LOCAL_RANK', str(args.device)))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(device)
+        dist.init_process_group('nccl')
+    t0 = time.perf_counter()
+    res = backtest(args.seasons, args.seed, args.simulations, device, rank, world)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(f"\n{'=' * 60}\nBacktest (offline sweep, synthetic weekend inputs, hand-entered outcomes)\n"
+              f"Seasons: {args.seasons}   simulations per race: {args.simulations}\n{'=' * 60}\n")
+        print(f"Races analyzed: {res['n_races']}   ({res['n_races'] * args.simulations / dt:,.0f} simulations/s overall)\n")
+        print('BRIER SCORES (lower = better, 0 = perfect)\n' + '-' * 40)
+        print(f"  Pole position: {res['pole_brier']:.4f}\n  Race winner:   {res['win_brier']:.4f}")
+        print(f"  (Random baseline: {0.0475:.4f})\n")
+        print('PODIUM ACCURACY\n' + '-' * 40 + f"\n  Correct podium picks: {res['podium_accuracy']:.1%}\n")
+        if args.json:
+            with open(args.json, 'w') as f:
+                json.dump(res, f)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog='monte_carlo_gp_amd', description='F1 race prediction on MI355X')
+    sub = ap.add_subparsers(dest='cmd', required=True)
+    p = sub.add_parser('predict', help='predict one race weekend (main.py of the reference)')
+    p.add_argument('--season', type=int, default=2025)
+    p.add_argument('--race', type=str, required=True)
+    p.add_argument('--prediction-point', type=str, default='fp2', choices=['fp1', 'fp2', 'fp3', 'quali', 'sprint'])
+    p.add_argument('--simulations', type=int, default=10000)
+    p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--offline', action='store_true', help='use the synthetic weekend fixture')
+    p.add_argument('--fixture', type=str, default=None, help='race fixture JSON (see predictor.py)')
+    p.add_argument('--device', type=int, default=0)
+    p.add_argument('--json', type=str, default=None)
+    p.set_defaults(fn=cmd_predict)
+    b = sub.add_parser('backtest', help='sweep a season and score it (backtest.py of the reference)')
+    b.add_argument('--seasons', type=int, nargs='+', default=[2024])
+    b.add_argument('--seed', type=int, default=42)
+    b.add_argument('--simulations', type=int, default=10000)
+    b.add_argument('--device', type=int, default=0)
+    b.add_argument('--json', type=str, default=None)
+    b.set_defaults(fn=cmd_backtest)
+    args = ap.parse_args(argv)
+    return args.fn(args)
+
+
+if __name__ == '__main__':
+    sys.exit(main())

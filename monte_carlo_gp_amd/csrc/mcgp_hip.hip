@@ -63,6 +63,7 @@ struct DeviceCtx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
+    char last_kernel[48] = "";
 };
 
 constexpr int kMaxDevices = 64;
@@ -266,6 +267,8 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     c.last_grid = grid;
     c.last_block = block;
     c.last_lds = lds;
+    if (is_reg) std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel_reg<%d>", kp.n);
+    else std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel");
     return MCGP_OK;
 }
 
@@ -389,6 +392,12 @@ int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out)
     HIP_TRY(hipEventSynchronize(c.ev_stop));
     HIP_TRY(hipEventElapsedTime(ms_out, c.ev_start, c.ev_stop));
     return MCGP_OK;
+}
+
+const char *mcgp_last_kernel_name(int32_t device)
+{
+    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready) return "";
+    return g_ctx[device].last_kernel;
 }
 
 int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads, uint32_t *lds_bytes)

@@ -31,6 +31,10 @@
 #ifndef MCGP_DUP
 #define MCGP_DUP 0
 #endif
+// Diagnostic: bit k set = leave section k out (results become wrong; timing only).
+#ifndef MCGP_SKIP
+#define MCGP_SKIP 0
+#endif
 
 #include <utility>
 
@@ -245,6 +249,9 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                 uint32_t sel;
                 if (fixed_grid) {
                     sel = fixed_grid[pos];
+                } else if (MCGP_SKIP & 4) {
+                    sel = (uint32_t)((pos * 7 + (int)(c0 & 3u)) % N);
+                    while (!((remaining >> sel) & 1u)) sel = (sel + 1u) % (uint32_t)N;
                 } else {
                     if ((pos & 3) == 0)
                         philox4x32_10(c0, c1, 0u, kPurposeGrid | (uint32_t)(pos >> 2), seed_lo, seed_hi, g0, g1, g2, g3);
@@ -342,7 +349,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
         // ================= laps 2..L, reference :166-228 =================
         int drs_disabled_until = 0;
 #pragma unroll 1
-        for (int lap = 2; lap <= L; ++lap) {
+        for (int lap = 2; lap <= ((MCGP_SKIP & 8) ? 1 : L); ++lap) {
             const int remaining_laps = L - lap;
             // ---- race-interrupting events, :168-176 ----
             {
@@ -356,7 +363,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                 const bool red = (uint64_t)e0 < P->t_red;
                 const bool sc = !red && (uint64_t)e1 < P->t_sc;
                 const bool vsc = !red && !sc && (uint64_t)e2 < P->t_vsc;
-                if (red || sc || vsc) {
+                if (!(MCGP_SKIP & 2) && (red || sc || vsc)) {
                     const bool dec_age = sc || (vsc && (uint64_t)e3 < P->t_vsc_tire);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     int k = 0;
@@ -466,7 +473,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             network_sort<N>(cum, pk);
             if (MCGP_DUP & 1) network_sort<N>(cum, pk);
 #pragma unroll 1
-            for (int pass = 0; pass < 3; ++pass) {
+            for (int pass = 0; pass < ((MCGP_SKIP & 1) ? 0 : 3); ++pass) {
                 double pace[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) {

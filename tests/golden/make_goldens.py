@@ -25,6 +25,8 @@ What is written (all data, no reference source text):
   sample_grid.npz       G5: _sample_grid outputs
   misc.json             G6: _predict_quali matrix inputs/outputs,
                         _create_race_config fields, brier_score values
+  weekend.json          predict_weekend's glue: the arguments it hands to
+                        run_monte_carlo for two offline weekends
   ref_stat_<case>.npz   big-N reference histograms (several seeds) for the
                         statistical link HIP-Philox ~ reference-MT
 """
@@ -342,6 +344,96 @@ def misc():
         json.dump(json.loads(json.dumps(out, default=float)), f, indent=0)
 
 
+def weekend():
+    """predict_weekend's numeric glue (reference src/predictor.py:186-319), captured offline.
+
+    The reference predictor is driven with stub data sources (no FastF1): a synthetic practice
+    DataFrame, canned feature dicts and weather.  RaceSimulator.run_monte_carlo is replaced by a
+    recorder, so the fixture holds exactly what the orchestrator hands to the hot path, plus the
+    practice-derived dicts (base_pace, tire_deg, tyre table) that an offline race fixture supplies.
+    """
+    import pandas as pd
+    import src.predictor as predictor_mod
+    rng = random.Random(7)
+    drivers = list(DRIVER_TEAMS.keys())
+    out = {}
+    for label, rain, point, actual in (('dry_fp2', False, 'fp2', False), ('damp_quali', True, 'quali', True)):
+        rows = []
+        for i, d in enumerate(drivers):
+            for lap in range(1, 13):
+                comp = ['SOFT', 'MEDIUM', 'HARD'][(lap + i) % 3]
+                t = 91.0 + 0.12 * i + 0.04 * lap + {'SOFT': -0.7, 'MEDIUM': 0.0, 'HARD': 0.5}[comp] + rng.gauss(0, 0.15)
+                rows.append(dict(Driver=d, LapTime=t, LapNumber=lap, Compound=comp))
+        fp = pd.DataFrame(rows)
+        race_feats = {d: dict(clutch_factor=rng.uniform(-1, 1), dnf_probability=rng.uniform(0.02, 0.12),
+                              team_trend=rng.uniform(-0.5, 0.5), wet_performance=rng.uniform(-1, 1)) for d in drivers}
+        quali_feats = {d: dict(teammate_delta=rng.uniform(-0.4, 0.4), form_score=rng.uniform(-1, 1),
+                               circuit_affinity=rng.uniform(-1, 1)) for d in drivers}
+        weather = dict(rainfall=rain, track_temp=31.5)
+
+        class Loader:
+            def load_season_data(self, season):
+                raise RuntimeError('offline')
+
+            def load_session(self, season, race, session):
+                return fp
+
+            def get_weather(self, season, race, session):
+                return weather
+
+        class Features:
+            def load_historical_data(self, seasons):
+                pass
+
+            def calculate_quali_features(self, d, race):
+                return quali_feats[d]
+
+            def calculate_race_features(self, d, race, w):
+                return race_feats[d]
+
+        p = F1Predictor.__new__(F1Predictor)
+        p.data_loader, p.feature_engine = Loader(), Features()
+        p.elo_system = F1EloSystem()
+        p.elo_system.ratings = {d: {'quali': 1650.0 - 13.0 * i, 'race': 1600.0} for i, d in enumerate(drivers)}
+        p._processed_seasons, p._features_loaded = set(), False
+        captured = {}
+
+        class Recorder:
+            def __init__(self, config):
+                captured['config'] = {k: getattr(config, k) for k in (
+                    'total_laps', 'pit_loss', 'overtake_delta', 'sc_probability', 'vsc_probability',
+                    'red_flag_probability', 'dnf_rates', 'drs_zones', 'drs_delta', 'tire_compounds',
+                    'driver_teams', 'dirty_air_threshold', 'dirty_air_penalty')}
+
+            def run_monte_carlo(self, **kw):
+                captured['call'] = kw
+                return {d: {i + 1: 1.0 if i == j else 0.0 for i in range(3)} for j, d in enumerate(drivers)}
+
+        saved = predictor_mod.RaceSimulator
+        predictor_mod.RaceSimulator = Recorder
+        try:
+            grid = {d: ((i * 7) % 20) + 1 for i, d in enumerate(drivers)} if actual else None
+            res = p.predict_weekend(2024, 'Monaco Grand Prix' if rain else 'Bahrain Grand Prix',
+                                    grid_penalties={'NOR': 'gearbox', 'HAM': 3}, prediction_point=point,
+                                    actual_grid=grid)
+        finally:
+            predictor_mod.RaceSimulator = saved
+        pace = p._extract_race_pace(fp)
+        out[label] = dict(
+            race='Monaco Grand Prix' if rain else 'Bahrain Grand Prix', prediction_point=point,
+            grid_penalties={'NOR': 'gearbox', 'HAM': 3}, actual_grid=grid, weather=weather,
+            drivers=drivers, quali_ratings={d: 1650.0 - 13.0 * i for i, d in enumerate(drivers)},
+            race_features=race_feats, quali_features=quali_feats,
+            practice=dict(base_pace=pace, tire_deg=p._extract_tire_deg(fp),
+                          tire_compounds=p._extract_tire_compound_deltas(fp)),
+            captured=captured,
+            result={k: res[k] for k in ('pole_probabilities', 'win_probabilities', 'podium_probabilities',
+                                        'prediction_point', 'confidence', 'grid_is_actual')},
+        )
+    with open(os.path.join(HERE, 'weekend.json'), 'w') as f:
+        json.dump(json.loads(json.dumps(out, default=float)), f, indent=0)
+
+
 def ref_stat(case, seeds, n_each):
     """Big-N reference histogram (one process per seed) for the statistical link."""
     import multiprocessing as mp
@@ -368,7 +460,7 @@ def _ref_stat_one(case, seed, n_each):
 
 
 def main():
-    what = sys.argv[1:] or ['cases', 'streams', 'grids', 'misc']
+    what = sys.argv[1:] or ['cases', 'streams', 'grids', 'misc', 'weekend']
     cases = build_cases()
     if 'cases' in what:
         meta = dict(
@@ -389,6 +481,8 @@ def main():
         sample_grids(cases)
     if 'misc' in what:
         misc()
+    if 'weekend' in what:
+        weekend()
     if 'stat' in what:
         by = {c['name']: c for c in cases}
         ref_stat(by['S60'], list(range(101, 109)), 25000)

@@ -6,9 +6,13 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/ablate.txt
 : > $out
-for dup in 0 1 2 4 8 16; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DMCGP_DUP=$dup \
-      -shared -o /tmp/libmcgp_dup$dup.so monte_carlo_gp_amd/csrc/mcgp_hip.hip
-  ms=$(MCGP_LIB=/tmp/libmcgp_dup$dup.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sims-per-step 4000000 2>/dev/null | python -c "import json,sys; print(json.load(sys.stdin)['roofline']['kernel_ms_avg'])")
-  echo "dup=$dup kernel_ms=$ms" | tee -a $out
+VARIANTS=${VARIANTS:-"DUP=0 DUP=1 DUP=2 DUP=4 DUP=8 SKIP=1 SKIP=2 SKIP=4 SKIP=8"}
+for v in $VARIANTS; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DMCGP_$v \
+      -shared -o /tmp/libmcgp_$v.so monte_carlo_gp_amd/csrc/mcgp_hip.hip &
+done
+wait
+for v in $VARIANTS; do
+  ms=$(MCGP_LIB=/tmp/libmcgp_$v.so MCGP_BENCH_NOCHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sims-per-step 4000000 2>/dev/null | python -c "import json,sys; print(json.load(sys.stdin)['roofline']['kernel_ms_avg'])")
+  echo "$v kernel_ms=$ms" | tee -a $out
 done

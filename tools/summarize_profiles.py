@@ -61,6 +61,10 @@ def main():
         traffic = dict(fetch_bytes_raw=allc['FETCH_SIZE'] * 1024, write_bytes=allc['WRITE_SIZE'] * 1024,
                        hbm_bytes_per_launch=(2 * allc['FETCH_SIZE'] + allc['WRITE_SIZE']) * 1024,
                        note='FETCH_SIZE doubled per the gfx950 correction; per launch of %g simulations' % sims)
+    if traffic:
+        with open(os.path.join(out_dir, 'traffic.json'), 'w') as f:
+            json.dump(dict(workload='S60', sims_per_launch=int(sims), source=f'{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE',
+                           **traffic), f, indent=1)
     with open(os.path.join(out_dir, f'{tag}_counters.json'), 'w') as f:
         json.dump(dict(kernel=meta, kernel_ms_avg=kernel_ms, sims_per_launch=sims, counters=allc, traffic=traffic),
                   f, indent=1)
