@@ -85,10 +85,18 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    # Rehearsal knobs (one-GPU box): MCGP_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and reduces over
+    # gloo instead of RCCL (RCCL refuses two ranks on one device).  Never set by the driver.
+    share = os.environ.get('MCGP_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     case, set_pop = load_workload(args.workload)
     cfg = RaceConfig(**case['config'])
@@ -114,10 +122,16 @@ def main():
                                     seed, local_rank, C.c_void_p(stream.cuda_stream),
                                     C.c_void_p(d_step.data_ptr()), None))
         if world > 1:
-            dist.all_reduce(d_step)            # RCCL over xGMI: 400 x int64, the path's only exchange
+            if share:
+                h = d_step.cpu()
+                dist.all_reduce(h)
+                d_step.copy_(h)
+            else:
+                dist.all_reduce(d_step)        # RCCL over xGMI: 400 x int64, the path's only exchange
         d_hist.add_(d_step)
 
     def sync():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -139,7 +153,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -163,7 +177,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            'metric': 'race-simulations/sec (20 drivers, 60 laps)',
+            'metric': f'race-simulations/sec ({n} drivers, {L} laps)',
             'value': total_sims / elapsed,
             'unit': 'race-simulations/s',
             'n_gpus': world,
