@@ -207,8 +207,9 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, uint64_t n_sim
                      uint32_t *lds)
 {
     const size_t per_thread = is_reg ? mcgp::per_thread_lds_bytes_reg((int)n) : mcgp::per_thread_lds_bytes((int)n);
+    const size_t shared = is_reg ? mcgp::shared_lds_bytes_reg((int)n) : mcgp::kSharedTableBytes;
     const size_t per_wave = 64 * per_thread;
-    int waves = (int)((c.lds_per_block - mcgp::kSharedTableBytes) / per_wave);
+    int waves = (int)((c.lds_per_block - shared) / per_wave);
     if (waves > 8) waves = 8;
     if (waves < 1) waves = 1;
     if (is_reg && waves > 4) waves = 4;        // __launch_bounds__(256): two such blocks share a CU
@@ -218,10 +219,14 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, uint64_t n_sim
         if (w >= 1 && w <= waves) waves = w;
     }
     {
-        const size_t blk = mcgp::kSharedTableBytes + (size_t)waves * per_wave;
+        const size_t blk = shared + (size_t)waves * per_wave;
         blocks_per_cu = (int)(c.lds_per_block / blk);
         if (blocks_per_cu < 1) blocks_per_cu = 1;
         if (blocks_per_cu * waves > 32) blocks_per_cu = 32 / waves;
+        if (const char *e = std::getenv("MCGP_MAX_BLOCKS_PER_CU")) {      // tuning / diagnostics
+            const int m = std::atoi(e);
+            if (m >= 1 && m < blocks_per_cu) blocks_per_cu = m;
+        }
     }
     uint32_t threads = (uint32_t)waves * 64u;
     if (n_sims < threads) threads = (uint32_t)(((n_sims + 63) / 64) * 64);
@@ -232,7 +237,7 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, uint64_t n_sim
     if (g < 1) g = 1;
     *grid = (uint32_t)g;
     *block = threads;
-    *lds = (uint32_t)(mcgp::kSharedTableBytes + (size_t)threads * per_thread);
+    *lds = (uint32_t)(shared + (size_t)threads * per_thread);
 }
 
 int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,

@@ -36,6 +36,7 @@
 #define MCGP_SKIP 0
 #endif
 
+
 #include <utility>
 
 namespace mcgp {
@@ -51,6 +52,13 @@ constexpr int k2IdShift = 22;                  // 5 bits, driver index
 constexpr int k2GposShift = 27;                // 5 bits, grid slot (most significant: tie-break)
 
 __host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)n * 12 + 16; }
+// block-shared tables of the register kernel: normal table, per-driver / per-compound constants,
+// n x n histogram (u32) and the transposed grid-probability matrix [slot][driver] (f64)
+__host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
+{
+    return (size_t)kNormalRows * 16 + 4 * kMaxCars * 8 + kMaxCars * 8 + 2 * kCompStride * 8 +
+           kMaxCars * kCompStride * 2 + (((size_t)n * n * 4 + 15) / 16) * 16 + (size_t)n * n * 8;
+}
 
 // Knuth, TAOCP 5.2.2 Algorithm M (merge exchange): a sorting network for any N.
 template <int N>
@@ -173,8 +181,11 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
     }
 }
 
+#ifndef MCGP_MIN_WAVES
+#define MCGP_MIN_WAVES 2
+#endif
 template <int N>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, MCGP_MIN_WAVES)
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                 uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
@@ -185,19 +196,19 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     const int L = P->total_laps;
     const int track = P->track;
 
-    // ---- LDS carve-up: same block-shared tables as race_kernel, then the per-lane rows ----
+    // ---- LDS carve-up: block-shared tables, then the per-lane rows ----
     float4 *t_norm = reinterpret_cast<float4 *>(smem);
     double *t_base = reinterpret_cast<double *>(smem + kNormalRows * 16);
     double *t_factor = t_base + kMaxCars;
     double *t_deg = t_factor + kMaxCars;
     double *t_var = t_deg + kMaxCars;
     unsigned long long *t_dnf = reinterpret_cast<unsigned long long *>(t_var + kMaxCars);
-    unsigned long long *t_dnf1 = t_dnf + kMaxCars;
-    double *t_cdeg = reinterpret_cast<double *>(t_dnf1 + kMaxCars);
+    double *t_cdeg = reinterpret_cast<double *>(t_dnf + kMaxCars);
     double *t_cdelta = t_cdeg + kCompStride;
     uint16_t *t_opt = reinterpret_cast<uint16_t *>(t_cdelta + kCompStride);
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(t_opt + kMaxCars * kCompStride);
-    double *s_last = reinterpret_cast<double *>(s_hist + kMaxCars * kMaxCars);   // [driver][lane]
+    double *t_grid = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(s_hist) + ((N * N * 4 + 15) / 16) * 16);  // [slot][driver]
+    double *s_last = t_grid + N * N;                                               // [driver][lane]
     uint32_t *s_word = reinterpret_cast<uint32_t *>(s_last + (size_t)N * B);       // [N + 4][lane]
     float *s_z = reinterpret_cast<float *>(s_word);
 
@@ -213,14 +224,16 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
         t_deg[i] = P->tire_deg[i];
         t_var[i] = P->variance[i];
         t_dnf[i] = P->t_dnf[i];
-        t_dnf1[i] = P->t_dnf1[i];
     }
     for (int i = tid; i < kCompStride; i += B) {
         t_cdeg[i] = P->comp_deg[i];
         t_cdelta[i] = P->comp_delta[i];
     }
     for (int i = tid; i < kMaxCars * kCompStride; i += B) t_opt[i] = P->opt_laps[i];
-    for (int i = tid; i < N * N; i += B) s_hist[i] = 0u;
+    for (int i = tid; i < N * N; i += B) {
+        s_hist[i] = 0u;
+        t_grid[(i % N) * N + (i / N)] = P->grid_probs[i];       // transposed: lanes gather by driver, conflict-free
+    }
     __syncthreads();
 
     const double pit_loss = P->pit_loss;
@@ -229,6 +242,28 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     const double dirty_thr = P->dirty_thr;
     const double dirty_pen = P->dirty_pen;
     const float kNaN = __uint_as_float(0x7fc00000u);
+    const uint32_t pop_sh = (uint32_t)P->pop_sh, pop_mh = (uint32_t)P->pop_mh;
+
+    // Everything the lap step of one slot reads from LDS, fetched in one batch.
+    struct SlotIn {
+        float z;
+        uint32_t opt;
+        double last, base, factor, var, cdeg, cdelta;
+    };
+    auto load_slot = [&](uint32_t p) -> SlotIn {
+        const uint32_t id = (p >> k2IdShift) & 31u;
+        const uint32_t comp = (p >> k2CompShift) & 7u;
+        SlotIn r;
+        r.z = ZED(id);
+        r.last = LAST(id);
+        r.base = t_base[id];
+        r.factor = t_factor[id];
+        r.var = t_var[id];
+        r.cdeg = t_cdeg[comp];
+        r.cdelta = t_cdelta[comp];
+        r.opt = t_opt[id * kCompStride + comp];
+        return r;
+    };
 
     for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
         const uint64_t local = (uint64_t)batch * (uint64_t)B + (uint64_t)tid;
@@ -257,37 +292,35 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                         philox4x32_10(c0, c1, 0u, kPurposeGrid | (uint32_t)(pos >> 2), seed_lo, seed_hi, g0, g1, g2, g3);
                     const uint32_t gw = (pos & 3) == 0 ? g0 : (pos & 3) == 1 ? g1 : (pos & 3) == 2 ? g2 : g3;
                     const double u = u32_to_unit(gw);
-                    double total = 0.0;
-#pragma unroll 1
-                    for (int d = 0; d < N; ++d) {
-                        const double p = ((remaining >> d) & 1u) ? P->grid_probs[d * N + pos] : 0.0;
-                        total = total + p;
-                    }
-                    double prob_sum = 0.0;
-#pragma unroll 1
-                    for (int d = 0; d < N; ++d) {
-                        const bool rem = (remaining >> d) & 1u;
-                        double p;
-                        if (total > 0) p = (rem ? P->grid_probs[d * N + pos] : 0.0) / total;
-                        else p = rem ? 1.0 / (double)n_remaining : 0.0;
+                    // Only the drivers still unplaced contribute (zeros add nothing to the sums and repeat
+                    // the running cdf), so each pass walks the `remaining` bit set: N - pos steps on every lane.
+                    const double *gcol = t_grid + pos * N;
+                    double total = 0.0;                                   // :119-123
+                    for (uint32_t m = remaining; m; m &= m - 1u) total = total + gcol[__ffs((int)m) - 1];
+                    double prob_sum = 0.0;                                // :125-133
+                    for (uint32_t m = remaining; m; m &= m - 1u) {
+                        const int d = __ffs((int)m) - 1;
+                        const double p = total > 0 ? gcol[d] / total : 1.0 / (double)n_remaining;
                         LAST(d) = p;
                         prob_sum = prob_sum + p;
                     }
-                    const bool renorm = prob_sum > 0 && fabs(prob_sum - 1.0) > 1e-9;
+                    const bool renorm = prob_sum > 0 && fabs(prob_sum - 1.0) > 1e-9;   // :134-135
+                    // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right')
                     double acc = 0.0;
-#pragma unroll 1
-                    for (int d = 0; d < N; ++d) {
+                    for (uint32_t m = remaining; m; m &= m - 1u) {
+                        const int d = __ffs((int)m) - 1;
                         double p = LAST(d);
                         if (renorm) p = p / prob_sum;
-                        acc = (d == 0) ? p : acc + p;
+                        acc = acc + p;
                         LAST(d) = acc;
                     }
                     const double cdf_last = acc;
-                    sel = 0;
-#pragma unroll 1
-                    for (int d = 0; d < N; ++d)
-                        if (LAST(d) / cdf_last <= u) sel = (uint32_t)d + 1u;
-                    if (sel >= (uint32_t)N) sel = (uint32_t)N - 1u;
+                    sel = (uint32_t)N;
+                    for (uint32_t m = remaining; m; m &= m - 1u) {        // first driver whose cdf exceeds u
+                        const int d = __ffs((int)m) - 1;
+                        if (sel == (uint32_t)N && !(LAST(d) / cdf_last <= u)) sel = (uint32_t)d;
+                    }
+                    if (sel >= (uint32_t)N) sel = 31u - (uint32_t)__clz((int)remaining);   // unreachable: cdf[-1] == 1 > u
                 }
                 if ((remaining >> sel) & 1u) { remaining &= ~(1u << sel); --n_remaining; }
                 WORD(pos) = sel;
@@ -405,41 +438,59 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             }
 
             // ---- this lap's draws, by driver pair: one Philox block = (dnf, noise) x 2 ----
+            // Two blocks per iteration: the two Philox chains interleave, and the four table look-ups
+            // of the inverse-normal transform go out as one batch.
 #pragma unroll 1
             for (int rep = 0; rep < ((MCGP_DUP & 2) ? 2 : 1); ++rep)
 #pragma unroll 1
-            for (int b = 0; b < (N + 1) / 2; ++b) {
-                uint32_t w0, w1, w2, w3;
+            for (int b = 0; b < (N + 1) / 2; b += 2) {
+                uint32_t w0, w1, w2, w3, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
                 philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (uint32_t)b, seed_lo, seed_hi, w0, w1, w2, w3);
-                const int d0 = 2 * b, d1 = 2 * b + 1;
-                ZED(d0) = ((uint64_t)w0 < P->t_dnf[d0]) ? kNaN : normal_from_u32(w1, t_norm);
-                if (d1 < N) ZED(d1) = ((uint64_t)w2 < P->t_dnf[d1]) ? kNaN : normal_from_u32(w3, t_norm);
+                const bool second = b + 1 < (N + 1) / 2;
+                if (second)
+                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (uint32_t)(b + 1), seed_lo, seed_hi, x0, x1, x2, x3);
+                const int d0 = 2 * b, d1 = 2 * b + 1, d2 = 2 * b + 2, d3 = 2 * b + 3;
+                const float z0 = normal_from_u32(w1, t_norm), z1 = normal_from_u32(w3, t_norm);
+                const float z2 = normal_from_u32(x1, t_norm), z3 = normal_from_u32(x3, t_norm);
+                const unsigned long long q0 = t_dnf[d0], q1 = t_dnf[d1 < N ? d1 : 0];
+                const unsigned long long q2 = t_dnf[d2 < N ? d2 : 0], q3 = t_dnf[d3 < N ? d3 : 0];
+                ZED(d0) = ((uint64_t)w0 < q0) ? kNaN : z0;
+                if (d1 < N) ZED(d1) = ((uint64_t)w2 < q1) ? kNaN : z1;
+                if (second) {
+                    ZED(d2) = ((uint64_t)x0 < q2) ? kNaN : z2;
+                    if (d3 < N) ZED(d3) = ((uint64_t)x2 < q3) ? kNaN : z3;
+                }
             }
 
             // ---- every running car's lap (:179-223) with its pit stop (:433-494), in time-rank order ----
+            // All LDS gathers of a slot (deviate, last lap, per-driver and per-compound constants) are issued
+            // in one batch, one slot ahead of their use, so the wave does not park on s_waitcnt per access.
             {
                 double fuel = 110.0 - 1.5 * (double)(lap - 1);
                 if (!(fuel > 0)) fuel = 0.0;
                 const double fuel_effect = (110.0 - fuel) * 0.03;
                 double carry = 0.0;
+                SlotIn cur = load_slot(pk[0]);
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
+                    SlotIn nxt = cur;
+                    if (i + 1 < N) nxt = load_slot(pk[i + 1]);
                     uint32_t p = pk[i];
                     if (!(p & k2Dnf)) {
                         const uint32_t id = (p >> k2IdShift) & 31u;
                         const double ahead_last = carry;
-                        carry = LAST(id);
-                        const float z = ZED(id);
+                        carry = cur.last;
+                        const float z = cur.z;
                         if (z != z) {
                             pk[i] = (p & ~k2AgeMask) | k2Dnf | (uint32_t)lap;
                         } else {
                             uint32_t comp = (p >> k2CompShift) & 7u;
                             uint32_t age = p & k2AgeMask;
-                            const double eff = t_cdeg[comp] * t_factor[id];
+                            const double eff = cur.cdeg * cur.factor;
                             const double tire = (double)age * eff;
                             const double drs_gain = (p & k2Drs) ? drs_delta : 0.0;
-                            const double noise = 0.0 + t_var[id] * (double)z;
-                            const double clean = t_base[id] + tire - fuel_effect + t_cdelta[comp] - drs_gain + noise;
+                            const double noise = 0.0 + cur.var * (double)z;
+                            const double clean = cur.base + tire - fuel_effect + cur.cdelta - drs_gain + noise;
                             double lap_time = clean;
                             if ((p & k2Dirty) && ahead_last > 0) {
                                 const double dirty_time = clean + dirty_pen;
@@ -447,13 +498,13 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                             }
                             double t = cum[i] + lap_time;
                             age += 1u;
-                            if ((int)age > (int)t_opt[id * kCompStride + comp] && remaining_laps > 5) {
+                            if ((int)age > (int)cur.opt && remaining_laps > 5) {
                                 t = t + pit_loss;
                                 uint32_t newc = stint_compound(track, remaining_laps);
                                 const uint32_t used_dry = (p >> k2UsedShift) & 7u;
                                 if (track == 0 && __popc(used_dry) == 1 && ((used_dry >> newc) & 1u)) {
                                     const uint32_t avail = 7u & ~used_dry;
-                                    const uint32_t popped = avail == 5u ? (uint32_t)P->pop_sh : avail == 6u ? (uint32_t)P->pop_mh : 0u;
+                                    const uint32_t popped = avail == 5u ? pop_sh : avail == 6u ? pop_mh : 0u;
                                     if (remaining_laps > 20) newc = (avail & 2u) ? 1u : popped;
                                     else newc = (avail & 1u) ? 0u : popped;
                                 }
@@ -466,6 +517,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                             pk[i] = (p & ~k2AgeMask) | age;
                         }
                     }
+                    cur = nxt;
                 }
             }
 
@@ -474,18 +526,23 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             if (MCGP_DUP & 1) network_sort<N>(cum, pk);
 #pragma unroll 1
             for (int pass = 0; pass < ((MCGP_SKIP & 1) ? 0 : 3); ++pass) {
-                double pace[N];
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const uint32_t id = (pk[i] >> k2IdShift) & 31u;
-                    pace[i] = t_base[id] + (double)(pk[i] & k2AgeMask) * t_deg[id];
-                }
+                // pace of every slot (:514-515) and the pace delta of every adjacent pair
+                double delta[N];
                 uint32_t cand = 0u;
+                {
+                    double pace_prev = 0.0;
 #pragma unroll
-                for (int i = 1; i < N; ++i) {
-                    double delta = pace[i - 1] - pace[i];
-                    if (pk[i] & k2Drs) delta += drs_delta;
-                    if (!((pk[i] | pk[i - 1]) & k2Dnf) && delta > overtake_delta) cand |= 1u << i;
+                    for (int i = 0; i < N; ++i) {
+                        const uint32_t id = (pk[i] >> k2IdShift) & 31u;
+                        const double pace = t_base[id] + (double)(pk[i] & k2AgeMask) * t_deg[id];
+                        if (i > 0) {
+                            double dl = pace_prev - pace;                                   // :516
+                            if (pk[i] & k2Drs) dl += drs_delta;                             // :519-520
+                            delta[i] = dl;
+                            if (!((pk[i] | pk[i - 1]) & k2Dnf) && dl > overtake_delta) cand |= 1u << i;   // :511,522
+                        }
+                        pace_prev = pace;
+                    }
                 }
                 if (cand == 0u) break;
                 // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4
@@ -500,26 +557,27 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     WORD(4 * b + 2) = o2;
                     WORD(4 * b + 3) = o3;
                 }
-                bool success = false;
+                // which attempts succeed (:523-524) does not depend on the times: all draw words are
+                // fetched in one batch and compared before the sequential write-back chain
+                uint32_t succ = 0u;
 #pragma unroll
                 for (int i = 1; i < N; ++i) {
-                    if ((cand >> i) & 1u) {
-                        const uint32_t k = __popc(cand & ((1u << i) - 1u));
-                        const uint32_t ow = WORD(k);
-                        double delta = pace[i - 1] - pace[i];
-                        if (pk[i] & k2Drs) delta += drs_delta;
-                        double prob = delta / 2.0;
-                        if (!(prob < 0.5)) prob = 0.5;
-                        if (u32_to_unit(ow) < prob) {
-                            double nb = cum[i - 1] - 0.1;
-                            if (!(nb > 0.1)) nb = 0.1;
-                            cum[i] = nb;
-                            cum[i - 1] = nb + 0.3;
-                            success = true;
-                        }
+                    const uint32_t ow = WORD(__popc(cand & ((1u << i) - 1u)));
+                    // u < min(0.5, delta / 2)  <=>  w < 2^31  and  w * 2^-31 < delta   (u = w * 2^-32, exact scalings)
+                    const bool hit = ow < 0x80000000u && (double)ow * (1.0 / 2147483648.0) < delta[i];
+                    if (((cand >> i) & 1u) && hit) succ |= 1u << i;
+                }
+                if (succ == 0u) break;
+                // :525-531, in sorted order, each pair seeing the previous pair's mutation (Q15)
+#pragma unroll
+                for (int i = 1; i < N; ++i) {
+                    if ((succ >> i) & 1u) {
+                        double nb = cum[i - 1] - 0.1;
+                        if (!(nb > 0.1)) nb = 0.1;
+                        cum[i] = nb;
+                        cum[i - 1] = nb + 0.3;
                     }
                 }
-                if (!success) break;
                 transposition_sort<N>(cum, pk);     // sorted again for the next pass / _update_positions
                 if (MCGP_DUP & 8) transposition_sort<N>(cum, pk);
             }
