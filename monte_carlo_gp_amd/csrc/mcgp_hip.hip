@@ -203,30 +203,52 @@ KernelFn select_kernel(uint32_t n, bool *is_reg)
 
 // Launch geometry: persistent blocks striding over batches of blockDim.x simulations; as many
 // waves per CU as LDS allows.
-void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, uint64_t n_sims, uint32_t *grid, uint32_t *block,
-                     uint32_t *lds)
+void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kernel, uint64_t n_sims, uint32_t *grid,
+                     uint32_t *block, uint32_t *lds)
 {
+    // waves per CU the kernel's register allocation admits: 4 SIMDs x floor(512 / VGPRs, granule 8), at most 8 each
+    int reg_cap = 8;
+    {
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) == hipSuccess && attr.numRegs > 0) {
+            const int alloc = ((attr.numRegs + 7) / 8) * 8;
+            int per_simd = 512 / alloc;
+            if (per_simd > 8) per_simd = 8;
+            if (per_simd < 1) per_simd = 1;
+            reg_cap = 4 * per_simd;
+        }
+    }
     const size_t per_thread = is_reg ? mcgp::per_thread_lds_bytes_reg((int)n) : mcgp::per_thread_lds_bytes((int)n);
     const size_t shared = is_reg ? mcgp::shared_lds_bytes_reg((int)n) : mcgp::kSharedTableBytes;
     const size_t per_wave = 64 * per_thread;
-    int waves = (int)((c.lds_per_block - shared) / per_wave);
-    if (waves > 8) waves = 8;
-    if (waves < 1) waves = 1;
-    if (is_reg && waves > 4) waves = 4;        // __launch_bounds__(256): two such blocks share a CU
-    int blocks_per_cu = 1;
-    if (const char *e = std::getenv("MCGP_WAVES_PER_BLOCK")) {
-        const int w = std::atoi(e);
-        if (w >= 1 && w <= waves) waves = w;
-    }
-    {
-        const size_t blk = shared + (size_t)waves * per_wave;
-        blocks_per_cu = (int)(c.lds_per_block / blk);
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-        if (blocks_per_cu * waves > 32) blocks_per_cu = 32 / waves;
-        if (const char *e = std::getenv("MCGP_MAX_BLOCKS_PER_CU")) {      // tuning / diagnostics
-            const int m = std::atoi(e);
-            if (m >= 1 && m < blocks_per_cu) blocks_per_cu = m;
+    int waves = 1, blocks_per_cu = 1;
+    if (is_reg) {
+        // blocks of <= 8 waves (__launch_bounds__(512, ..)); take the (waves per block, blocks per CU)
+        // pair that keeps most waves resident within the LDS budget and the register cap; among equals
+        // prefer at least 4 waves per block (fewer copies of the shared tables), then the smaller block
+        int best = 0;
+        for (int w = 1; w <= 8; ++w) {
+            int b = (int)(c.lds_per_block / (shared + (size_t)w * per_wave));
+            if (b * w > reg_cap) b = reg_cap / w;
+            if (b >= 1 && (b * w > best || (b * w == best && waves < 4))) { best = b * w; waves = w; blocks_per_cu = b; }
         }
+    } else {
+        waves = (int)((c.lds_per_block - shared) / per_wave);
+        if (waves > 8) waves = 8;
+        if (waves < 1) waves = 1;
+    }
+    if (const char *e = std::getenv("MCGP_WAVES_PER_BLOCK")) {          // tuning / diagnostics
+        const int w = std::atoi(e);
+        if (w >= 1 && w <= waves) {
+            waves = w;
+            blocks_per_cu = (int)(c.lds_per_block / (shared + (size_t)waves * per_wave));
+            if (blocks_per_cu < 1) blocks_per_cu = 1;
+            if (blocks_per_cu * waves > reg_cap) blocks_per_cu = reg_cap / waves;
+        }
+    }
+    if (const char *e = std::getenv("MCGP_MAX_BLOCKS_PER_CU")) {
+        const int m = std::atoi(e);
+        if (m >= 1 && m < blocks_per_cu) blocks_per_cu = m;
     }
     uint32_t threads = (uint32_t)waves * 64u;
     if (n_sims < threads) threads = (uint32_t)(((n_sims + 63) / 64) * 64);
@@ -247,7 +269,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     uint32_t grid, block, lds;
     bool is_reg = false;
     const KernelFn kernel = select_kernel((uint32_t)kp.n, &is_reg);
-    launch_geometry(c, (uint32_t)kp.n, is_reg, n_sims, &grid, &block, &lds);
+    launch_geometry(c, (uint32_t)kp.n, is_reg, kernel, n_sims, &grid, &block, &lds);
     const uint64_t n_batches = (n_sims + block - 1) / block;
     if (n_batches > 0xffffffffull) return fail(MCGP_E_BAD_ARG, "n_sims too large for one launch");
     DeviceCtx::Slot *sl = nullptr;

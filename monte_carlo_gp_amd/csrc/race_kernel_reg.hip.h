@@ -185,7 +185,7 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
 #define MCGP_MIN_WAVES 2
 #endif
 template <int N>
-__global__ void __launch_bounds__(256, MCGP_MIN_WAVES)
+__global__ void __launch_bounds__(512, MCGP_MIN_WAVES)
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                 uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
