@@ -39,7 +39,7 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 // Field sizes with a register-resident instantiation; every other n runs the generic LDS kernel.
-#define MCGP_REG_SIZES(X) X(10) X(18) X(19) X(20) X(21) X(22)
+#define MCGP_REG_SIZES(X) X(10) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
 
 constexpr int kParamSlots = 4;
 

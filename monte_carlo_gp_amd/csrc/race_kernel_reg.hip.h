@@ -526,22 +526,38 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             if (MCGP_DUP & 1) network_sort<N>(cum, pk);
 #pragma unroll 1
             for (int pass = 0; pass < ((MCGP_SKIP & 1) ? 0 : 3); ++pass) {
-                // pace of every slot (:514-515) and the pace delta of every adjacent pair
+                // pace of every slot (:514-515) and the pace delta of every adjacent pair.  The per-driver
+                // constants are gathered half a field at a time (one s_waitcnt per half, not per slot).
                 double delta[N];
                 uint32_t cand = 0u;
                 {
+                    constexpr int H = (N + 1) / 2;
                     double pace_prev = 0.0;
 #pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const uint32_t id = (pk[i] >> k2IdShift) & 31u;
-                        const double pace = t_base[id] + (double)(pk[i] & k2AgeMask) * t_deg[id];
-                        if (i > 0) {
-                            double dl = pace_prev - pace;                                   // :516
-                            if (pk[i] & k2Drs) dl += drs_delta;                             // :519-520
-                            delta[i] = dl;
-                            if (!((pk[i] | pk[i - 1]) & k2Dnf) && dl > overtake_delta) cand |= 1u << i;   // :511,522
+                    for (int h = 0; h < N; h += H) {
+                        double pb[H], pd[H];
+#pragma unroll
+                        for (int j = 0; j < H; ++j) {
+                            if (h + j < N) {
+                                const uint32_t id = (pk[h + j] >> k2IdShift) & 31u;
+                                pb[j] = t_base[id];
+                                pd[j] = t_deg[id];
+                            }
                         }
-                        pace_prev = pace;
+#pragma unroll
+                        for (int j = 0; j < H; ++j) {
+                            const int i = h + j;
+                            if (i < N) {
+                                const double pace = pb[j] + (double)(pk[i] & k2AgeMask) * pd[j];
+                                if (i > 0) {
+                                    double dl = pace_prev - pace;                                   // :516
+                                    if (pk[i] & k2Drs) dl += drs_delta;                             // :519-520
+                                    delta[i] = dl;
+                                    if (!((pk[i] | pk[i - 1]) & k2Dnf) && dl > overtake_delta) cand |= 1u << i;   // :511,522
+                                }
+                                pace_prev = pace;
+                            }
+                        }
                     }
                 }
                 if (cand == 0u) break;
@@ -559,12 +575,14 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                 }
                 // which attempts succeed (:523-524) does not depend on the times: all draw words are
                 // fetched in one batch and compared before the sequential write-back chain
+                uint32_t ow[N];
+#pragma unroll
+                for (int i = 1; i < N; ++i) ow[i] = WORD(__popc(cand & ((1u << i) - 1u)));
                 uint32_t succ = 0u;
 #pragma unroll
                 for (int i = 1; i < N; ++i) {
-                    const uint32_t ow = WORD(__popc(cand & ((1u << i) - 1u)));
                     // u < min(0.5, delta / 2)  <=>  w < 2^31  and  w * 2^-31 < delta   (u = w * 2^-32, exact scalings)
-                    const bool hit = ow < 0x80000000u && (double)ow * (1.0 / 2147483648.0) < delta[i];
+                    const bool hit = ow[i] < 0x80000000u && (double)ow[i] * (1.0 / 2147483648.0) < delta[i];
                     if (((cand >> i) & 1u) && hit) succ |= 1u << i;
                 }
                 if (succ == 0u) break;

@@ -53,9 +53,10 @@ def test_generic_and_register_kernels_agree(require_gpu, monkeypatch):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 7, 23, 32])
-def test_field_sizes_without_register_instantiation(require_gpu, n):
-    """Generic kernel, every field size up to the ABI maximum, ragged/zero grid columns (Q18 fallback)."""
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 19, 24, 25, 32])
+def test_other_field_sizes(require_gpu, n):
+    """Field sizes beyond the golden cases (generic LDS kernel and further register instantiations),
+    up to the ABI maximum, with an all-zero grid column (Q18 uniform fallback)."""
     rng = np.random.default_rng(n)
     drivers = [f'D{i:02d}' for i in range(n)]
     base = O.load_case('S60')
