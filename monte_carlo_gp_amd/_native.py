@@ -46,7 +46,7 @@ class McgpDrivers(C.Structure):
 
 def build(force=False):
     """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ('mcgp_hip.hip', 'race_kernel.hip.h', 'race_kernel_reg.hip.h', 'normal_table.h')]
+    srcs = [os.path.join(CSRC, f) for f in ('mcgp_hip.hip', 'reg_inst.hip', 'race_common.hip.h', 'race_kernel.hip.h', 'race_kernel_reg.hip.h', 'normal_table.h', 'Makefile')]
     srcs.append(os.path.join(os.path.dirname(_PKG), 'include', 'mcgp.h'))
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))

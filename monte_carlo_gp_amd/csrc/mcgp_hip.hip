@@ -39,7 +39,11 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 // Field sizes with a register-resident instantiation; every other n runs the generic LDS kernel.
+#ifdef MCGP_ONLY_N20      // diagnostic builds (tools/ablate.sh)
+#define MCGP_REG_SIZES(X) X(20)
+#else
 #define MCGP_REG_SIZES(X) X(10) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+#endif
 
 constexpr int kParamSlots = 4;
 
@@ -187,6 +191,19 @@ int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
 
 using KernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, uint32_t, unsigned long long *,
                           uint8_t *, const uint8_t *, uint32_t);
+
+}  // namespace
+
+// The register-resident instantiations are compiled one per translation unit (reg_inst.hip,
+// -DMCGP_INST_N=<n>) so that the build runs in parallel; here they are only declared.
+namespace mcgp {
+#define X(N_) extern template __global__ void race_kernel_reg<N_>(const KParams *, uint64_t, uint64_t, uint32_t, uint32_t, \
+                                                                  unsigned long long *, uint8_t *, const uint8_t *, uint32_t);
+MCGP_REG_SIZES(X)
+#undef X
+}  // namespace mcgp
+
+namespace {
 
 KernelFn select_kernel(uint32_t n, bool *is_reg)
 {

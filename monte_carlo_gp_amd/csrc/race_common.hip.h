@@ -1,0 +1,107 @@
+// race_common.hip.h -- pieces shared by the race kernels: the parameter block, the Philox4x32-10
+// block function, the inverse-normal transform and the tyre-compound rule.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcgp {
+
+constexpr int kMaxCars = 32;
+constexpr int kNormalRows = 448;
+constexpr int kCompStride = 8;
+
+// Philox counter word 3 = purpose << 16 | index   (the oracle uses the same map)
+constexpr uint32_t kPurposeGrid = 0u << 16;
+constexpr uint32_t kPurposeEvent = 1u << 16;
+constexpr uint32_t kPurposeCar = 2u << 16;
+constexpr uint32_t kPurposeOvt = 3u << 16;
+
+// pk word layout
+constexpr uint32_t kAgeMask = 0x3FFu;          // tyre age; lap of retirement once dnf is set
+constexpr int kCompShift = 10;                 // 3 bits
+constexpr int kUsedShift = 13;                 // 5 bits, one per compound
+constexpr int kGposShift = 18;                 // 5 bits, grid slot
+constexpr uint32_t kDnf = 1u << 23;
+constexpr uint32_t kDrs = 1u << 24;
+constexpr uint32_t kDirty = 1u << 25;          // 0 < time_behind_leader < dirty_air_threshold
+
+// Read-only problem description, resident in device memory, uniform across lanes.
+struct KParams {
+    int32_t n, total_laps, track, pop_sh, pop_mh, pad0;
+    double pit_loss, overtake_delta, drs_delta, dirty_thr, dirty_pen;
+    // u < p  <=>  w < ceil(p * 2^32) for the 32-bit uniform u = w / 2^32
+    uint64_t t_red, t_sc, t_vsc, t_vsc_tire;
+    double comp_deg[kCompStride], comp_delta[kCompStride];
+    double base_pace[kMaxCars];
+    double factor[kMaxCars];        // deg / 0.05 if deg > 0 else 1.0      reference :321
+    double tire_deg[kMaxCars];      // overtake pace                        reference :514
+    double variance[kMaxCars];
+    uint64_t t_dnf1[kMaxCars];      // lap 1: team rate * 4.0               reference :286-287
+    uint64_t t_dnf[kMaxCars];       // laps >= 2                            reference :190-194
+    uint16_t opt_laps[kMaxCars * kCompStride];   // pit threshold per driver and compound  :454-462
+    double grid_probs[kMaxCars * kMaxCars];      // [driver][slot], row stride n
+    uint32_t normal_bits[kNormalRows * 4];
+};
+
+// LDS bytes: block-shared tables, then per-thread rows.
+constexpr size_t kSharedTableBytes =
+    kNormalRows * 16            // inverse-normal cubic rows (float4)
+    + 4 * kMaxCars * 8          // base_pace, factor, tire_deg, variance
+    + 2 * kMaxCars * 8          // t_dnf, t_dnf1
+    + kMaxCars * kCompStride * 2   // opt_laps
+    + 2 * kCompStride * 8       // comp_deg, comp_delta
+    + kMaxCars * kMaxCars * 4;  // histogram
+__host__ __device__ constexpr size_t per_thread_lds_bytes(int n) { return (size_t)n * (8 + 8 + 4 + 1); }
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1,
+                                              uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+// One 32-bit word -> N(0,1): piecewise-cubic inverse CDF (tools/gen_normal_table.py).
+__device__ __forceinline__ float normal_from_u32(uint32_t w, const float4 *__restrict__ tab)
+{
+    const uint32_t m = w & 0x7fffffffu;
+    const bool small = m < 16u;
+    const uint32_t mm = small ? 16u : m;
+    const int sh = 27 - __clz((int)mm);                 // floor(log2 mm) - 4
+    const uint32_t k = (mm >> sh) & 15u;
+    const uint32_t r = mm & ((1u << sh) - 1u);
+    float t = ((float)r + 0.5f) * __uint_as_float((uint32_t)(127 - sh) << 23);
+    t = small ? 0.0f : t;
+    const uint32_t row = small ? m : 16u + 16u * (uint32_t)sh + k;
+    const float4 c = tab[row];
+    float z = __builtin_fmaf(c.w, t, c.z);
+    z = __builtin_fmaf(z, t, c.y);
+    z = __builtin_fmaf(z, t, c.x);
+    return (w >> 31) ? -z : z;
+}
+
+__device__ __forceinline__ double u32_to_unit(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
+
+__device__ __forceinline__ uint32_t stint_compound(int track, int remaining_laps)
+{
+    // reference :420-429 and :469-478
+    if (track == 2) return 4u;           // wet -> WET
+    if (track == 1) return 3u;           // damp -> INTERMEDIATE
+    if (remaining_laps > 30) return 2u;  // HARD
+    if (remaining_laps > 15) return 1u;  // MEDIUM
+    return 0u;                           // SOFT
+}
+
+}  // namespace mcgp

@@ -24,7 +24,7 @@
 // generated in a driver-indexed pre-pass with wave-uniform thresholds, so the per-lap RNG
 // cost is N/2 + 1 Philox calls plus one per four overtake attempts.
 #pragma once
-#include "race_kernel.hip.h"
+#include "race_common.hip.h"
 
 // Diagnostic builds only (tools/ablate.sh): bit k set = run section k twice (each section is
 // idempotent, results unchanged) so its cost shows up as a time difference.  0 in the product build.
@@ -243,6 +243,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     const double dirty_pen = P->dirty_pen;
     const float kNaN = __uint_as_float(0x7fc00000u);
     const uint32_t pop_sh = (uint32_t)P->pop_sh, pop_mh = (uint32_t)P->pop_mh;
+    const uint64_t t_red = P->t_red, t_sc = P->t_sc, t_vsc = P->t_vsc, t_vsc_tire = P->t_vsc_tire;
 
     // Everything the lap step of one slot reads from LDS, fetched in one batch.
     struct SlotIn {
@@ -393,11 +394,11 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     philox4x32_10(c0 ^ e0, c1, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, f0, f1, f2, f3);
                     if ((f0 | f1 | f2 | f3) == 0u) e0 = f0;     // never true in practice; keeps the block alive
                 }
-                const bool red = (uint64_t)e0 < P->t_red;
-                const bool sc = !red && (uint64_t)e1 < P->t_sc;
-                const bool vsc = !red && !sc && (uint64_t)e2 < P->t_vsc;
+                const bool red = (uint64_t)e0 < t_red;
+                const bool sc = !red && (uint64_t)e1 < t_sc;
+                const bool vsc = !red && !sc && (uint64_t)e2 < t_vsc;
                 if (!(MCGP_SKIP & 2) && (red || sc || vsc)) {
-                    const bool dec_age = sc || (vsc && (uint64_t)e3 < P->t_vsc_tire);
+                    const bool dec_age = sc || (vsc && (uint64_t)e3 < t_vsc_tire);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     int k = 0;
                     double leader = 0.0, prev_nt = -1.0;

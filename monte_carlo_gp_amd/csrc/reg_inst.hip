@@ -1,0 +1,13 @@
+// reg_inst.hip -- one explicit instantiation of the register-resident race kernel per object file.
+// Built as reg_inst_<n>.o with -DMCGP_INST_N=<n> (see Makefile); the sizes must match
+// MCGP_REG_SIZES in mcgp_hip.hip.
+#include "race_kernel_reg.hip.h"
+
+#ifndef MCGP_INST_N
+#error "compile with -DMCGP_INST_N=<field size>"
+#endif
+
+namespace mcgp {
+template __global__ void race_kernel_reg<MCGP_INST_N>(const KParams *, uint64_t, uint64_t, uint32_t, uint32_t,
+                                                      unsigned long long *, uint8_t *, const uint8_t *, uint32_t);
+}  // namespace mcgp

@@ -8,8 +8,9 @@ out=gpurun_out/ablate.txt
 : > $out
 VARIANTS=${VARIANTS:-"DUP=0 DUP=1 DUP=2 DUP=4 DUP=8 SKIP=1 SKIP=2 SKIP=4 SKIP=8"}
 for v in $VARIANTS; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DMCGP_$v \
-      -shared -o /tmp/libmcgp_$v.so monte_carlo_gp_amd/csrc/mcgp_hip.hip &
+  ( mkdir -p /tmp/abl_$v && cd monte_carlo_gp_amd/csrc && \
+    make -s -j8 BUILD=/tmp/abl_$v OUT=/tmp/libmcgp_$v.so REG_SIZES=20 \
+      HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DMCGP_$v -DMCGP_ONLY_N20" /tmp/libmcgp_$v.so ) &
 done
 wait
 for v in $VARIANTS; do
