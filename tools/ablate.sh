@@ -1,19 +1,33 @@
 #!/bin/bash
-# Diagnostic: build libmcgp_hip variants with one section duplicated (MCGP_DUP bit) and time each.
-# Run on the GPU box:  bash tools/ablate.sh   -> gpurun_out/ablate.txt
+# Diagnostic A/B of kernel variants on ONE GPU box (device-to-device variance is several %).
+#   tools/ablate.sh build   (in the build container: hipcc cross-compiles)  -> abl/libmcgp_<variant>.so
+#   tools/ablate.sh run     (on the GPU box, via gpurun)                    -> gpurun_out/ablate.txt
+# VARIANTS are -DMCGP_<name>=<value> switches of race_kernel_reg.hip.h:
+#   DUP=k   run section k twice (idempotent, results unchanged): its cost shows as a time difference
+#   SKIP=k  leave section k out (results wrong): timing only
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out
-out=gpurun_out/ablate.txt
-: > $out
 VARIANTS=${VARIANTS:-"DUP=0 DUP=1 DUP=2 DUP=4 DUP=8 SKIP=1 SKIP=2 SKIP=4 SKIP=8"}
-for v in $VARIANTS; do
-  ( mkdir -p /tmp/abl_$v && cd monte_carlo_gp_amd/csrc && \
-    make -s -j8 BUILD=/tmp/abl_$v OUT=/tmp/libmcgp_$v.so REG_SIZES=20 \
-      HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DMCGP_$v -DMCGP_ONLY_N20" /tmp/libmcgp_$v.so ) &
-done
-wait
-for v in $VARIANTS; do
-  ms=$(MCGP_LIB=/tmp/libmcgp_$v.so MCGP_BENCH_NOCHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sims-per-step 4000000 2>/dev/null | python -c "import json,sys; print(json.load(sys.stdin)['roofline']['kernel_ms_avg'])")
-  echo "$v kernel_ms=$ms" | tee -a $out
-done
+case "$1" in
+build)
+  mkdir -p abl
+  root=$PWD
+  for v in $VARIANTS; do
+    name=${v//=/_}          # no '=' in a make goal: make would read it as a variable assignment
+    ( cd monte_carlo_gp_amd/csrc && make -s -j8 BUILD=/tmp/abl_$name OUT=$root/abl/libmcgp_$name.so REG_SIZES=20 \
+        HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DMCGP_$v -DMCGP_ONLY_N20" \
+        $root/abl/libmcgp_$name.so )
+  done ;;
+run)
+  mkdir -p gpurun_out
+  out=gpurun_out/ablate.txt
+  : > $out
+  for rep in 1 2; do
+    for v in $VARIANTS; do
+      ms=$(MCGP_LIB=$PWD/abl/libmcgp_${v//=/_}.so MCGP_BENCH_NOCHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline \
+           --sims-per-step ${SIMS:-4000000} 2>/dev/null | python -c "import json,sys; print(json.load(sys.stdin)['roofline']['kernel_ms_avg'])")
+      echo "$v kernel_ms=$ms" | tee -a $out
+    done
+  done ;;
+*) echo "usage: $0 build|run"; exit 2 ;;
+esac
