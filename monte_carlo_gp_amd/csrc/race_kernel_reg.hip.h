@@ -133,6 +133,18 @@ __device__ __forceinline__ bool in_order(const double (&cum)[N], const uint32_t 
     return !bad;
 }
 
+// After a round that ends with the odd pairs (1,2), (3,4), .. those pairs are in order by
+// construction; the field is in order iff the even pairs (0,1), (2,3), .. still are.
+template <int N>
+__device__ __forceinline__ bool even_pairs_in_order(const double (&cum)[N], const uint32_t (&pk)[N])
+{
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i + 1 < N; i += 2)
+        bad |= (cum[i] > cum[i + 1]) || (cum[i] == cum[i + 1] && pk[i] > pk[i + 1]);
+    return !bad;
+}
+
 // Odd-even transposition rounds until the field is in order: the re-sort after a LOCAL
 // perturbation (an overtake pass moves a few cars by 0.1-0.3 s).
 template <int N>
@@ -143,7 +155,18 @@ __device__ __forceinline__ void transposition_sort(double (&cum)[N], uint32_t (&
         for (int i = 0; i + 1 < N; i += 2) (void)cmpx(cum[i], pk[i], cum[i + 1], pk[i + 1]);
 #pragma unroll
         for (int i = 1; i + 1 < N; i += 2) (void)cmpx(cum[i], pk[i], cum[i + 1], pk[i + 1]);
-    } while (!in_order<N>(cum, pk));
+    } while (!even_pairs_in_order<N>(cum, pk));
+}
+
+// After the time-only network the field is ordered by time; only equal times can still be in the
+// wrong (grid) order.
+template <int N>
+__device__ __forceinline__ bool ties_in_order(const double (&cum)[N], const uint32_t (&pk)[N])
+{
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i + 1 < N; ++i) bad |= (cum[i] == cum[i + 1]) && pk[i] > pk[i + 1];
+    return !bad;
 }
 
 // Full sort by (cumulative_time, grid slot): Python's stable sorted() of the reference (:506 etc.).
@@ -154,7 +177,7 @@ __device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N]
 {
     constexpr MergeExchange<N> net{};
     network_sort_impl<N>(cum, pk, std::make_index_sequence<(size_t)net.n>{});
-    if (!in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
+    if (!ties_in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
 }
 
 // _update_positions, reference :538-560.
