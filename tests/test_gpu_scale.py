@@ -72,3 +72,24 @@ def test_statistical_link_oracle_mt_large(require_gpu):
     se = np.sqrt(np.maximum(p_gpu * (1 - p_gpu), 1e-12) * (1 / n_mt + 1 / n_gpu))
     assert np.all(np.abs(p_mt - p_gpu) <= 4.5 * se + 5e-5), float(np.max(np.abs(p_mt - p_gpu) / (se + 1e-12)))
     assert abs(p_mt[0, 0] - p_gpu[0, 0]) < 4.5 * se[0, 0]          # VER win probability
+
+
+@pytest.mark.parametrize('name', ['S50', 'EVT', 'HET', 'DMP', 'N10'])
+def test_statistical_link_other_cases(require_gpu, name):
+    """Link 3 on the remaining golden configurations (event storm, heterogeneous 21-car field,
+    rain, 10-car field, the set.pop()-sensitive 50-lap race): 2e5 oracle-MT simulations (8 seeds)
+    against 1e7 HIP-Philox simulations, every cell within 4.5 SE + 1e-4."""
+    from concurrent.futures import ThreadPoolExecutor
+    case = O.load_case(name)
+
+    def one(seed):
+        return O.Problem(case).run(25_000, rng=O.RNG_MT, seed=seed)['hist']
+    with ThreadPoolExecutor(8) as ex:
+        h_mt = sum(ex.map(one, range(500, 508)))
+    n_mt, n_gpu = 200_000, 10_000_000
+    hist, _, _ = product_run(case, n_gpu, 31337)
+    _check_latin(hist, n_gpu)
+    p_mt, p_gpu = h_mt / n_mt, hist / n_gpu
+    se = np.sqrt(np.maximum(p_gpu * (1 - p_gpu), 1e-12) * (1 / n_mt + 1 / n_gpu))
+    worst = float(np.max(np.abs(p_mt - p_gpu) / (se + 1e-12)))
+    assert np.all(np.abs(p_mt - p_gpu) <= 4.5 * se + 1e-4), (name, worst)

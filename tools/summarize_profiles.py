@@ -96,6 +96,37 @@ def main():
     if kernel_ms:
         simd_cycles = 1024 * kernel_ms * 1e-3 * 2.4e9
         lines.append(f'| VALU instructions / (1024 SIMDs x kernel time x 2.4 GHz) | {g("SQ_INSTS_VALU") / simd_cycles:.3f} per SIMD-cycle |')
+    abl = os.path.join(ROOT, 'gpurun_out', 'ablate.txt')
+    if os.path.exists(abl):
+        vals = collections.defaultdict(list)
+        for line in open(abl):
+            k, _, v = line.strip().partition(' kernel_ms=')
+            if v:
+                vals[k].append(float(v))
+        if 'DUP=0' in vals:
+            shutil.copy(abl, os.path.join(out_dir, f'{tag}_ablate.txt'))
+            base = sum(vals['DUP=0']) / len(vals['DUP=0'])
+            names = {'DUP=1': 'sorting network after the lap step (run twice)', 'DUP=2': 'per-lap RNG pre-pass: 10 Philox blocks + 20 deviates (run twice)',
+                     'DUP=4': '_update_positions (run twice)', 'DUP=8': 'one extra transposition re-sort per successful overtake pass',
+                     'SKIP=1': 'overtake pass loop left out', 'SKIP=2': 'event handlers left out', 'SKIP=4': 'grid sampling left out',
+                     'SKIP=8': 'laps 2..L left out (grid + lap 1 + classification remain)'}
+            lines += ['', f'## Where the time goes (tools/ablate.sh, same box, 4e6 simulations, baseline {base:.2f} ms)', '',
+                      'DUP = section run twice (idempotent, results unchanged); SKIP = section left out (timing only).', '',
+                      '| variant | kernel ms | share of baseline |', '|---|---|---|']
+            for k in ('DUP=1', 'DUP=2', 'DUP=4', 'DUP=8', 'SKIP=1', 'SKIP=2', 'SKIP=4', 'SKIP=8'):
+                if k in vals:
+                    m = sum(vals[k]) / len(vals[k])
+                    share = (m - base) / base if k.startswith('DUP') else (base - m) / base
+                    if k == 'SKIP=8':
+                        share = m / base
+                    lines.append(f'| {k}: {names[k]} | {m:.2f} | {share:.1%} |')
+    mb = os.path.join(out_dir, f'{tag}_mapping_microbench.json')
+    if os.path.exists(mb):
+        d = json.load(open(mb))
+        lines += ['', '## Lane mapping, ordering step only (tools/mapping_microbench.hip)', '',
+                  f'* lane-per-car, rank by counting over ds_bpermute, 3 races per wave: {d["lane_per_car"]["ordering_steps_per_s"]:.3g} field sorts/s',
+                  f'* lane-per-race, 97-comparator network in VGPRs, 64 races per wave: {d["lane_per_race"]["ordering_steps_per_s"]:.3g} field sorts/s '
+                  f'(**{d["ratio_race_over_car"]:.1f}x**)']
     with open(os.path.join(out_dir, f'{tag}_summary.md'), 'w') as f:
         f.write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
