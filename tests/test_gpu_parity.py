@@ -120,3 +120,32 @@ def test_histogram_accumulates_and_orders_optional(require_gpu):
                                  h.ctypes.data_as(C.POINTER(C.c_uint64)), None))
     ref = O.Problem(case).run(1000, rng=O.RNG_PHILOX, seed=21)
     assert np.array_equal(h.astype(np.int64), ref['hist'])
+
+
+def test_orders_across_the_staging_chunk_boundary(require_gpu):
+    """mcgp_run stages per-simulation orders in chunks of 2^22 simulations: check both sides of the seam."""
+    case = O.load_case('N10')
+    n_sims = (1 << 22) + 1500
+    hist, _, orders = product_run(case, n_sims, 8, orders=True)
+    P = O.Problem(case)
+    for off, cnt in ((0, 1000), ((1 << 22) - 700, 1400), (n_sims - 500, 500)):
+        ref = P.run(cnt, rng=O.RNG_PHILOX, seed=8, sim_offset=off, want_orders=True)
+        assert np.array_equal(orders[off:off + cnt], ref['orders']), off
+    # the histogram is the column-wise count of the orders
+    h = np.zeros_like(hist)
+    for p in range(P.n):
+        h[:, p] = np.bincount(orders[:, p], minlength=P.n)
+    assert np.array_equal(h, hist)
+
+
+def test_concurrent_calls_from_two_threads(require_gpu):
+    """The C ABI is blocking and re-entrant (one mutex-guarded context per device)."""
+    from concurrent.futures import ThreadPoolExecutor
+    cases = [O.load_case('S50'), O.load_case('WET')]
+
+    def work(i):
+        return product_run(cases[i % 2], 20000, 100 + i)[0]
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(work, range(8)))
+    for i, h in enumerate(got):
+        assert np.array_equal(h, O.Problem(cases[i % 2]).run(20000, rng=O.RNG_PHILOX, seed=100 + i)['hist']), i
