@@ -27,6 +27,9 @@ What is written (all data, no reference source text):
                         _create_race_config fields, brier_score values
   weekend.json          predict_weekend's glue: the arguments it hands to
                         run_monte_carlo for two offline weekends
+  fuzz_cases.json,      72 random configurations over the whole input space (field
+  fuzz.npz              size 2..24, rain, missing dict entries, event storms, ...) and the
+                        reference's finishing orders / sampled grids for 40 runs of each
   ref_stat_<case>.npz   big-N reference histograms (several seeds) for the
                         statistical link HIP-Philox ~ reference-MT
 """
@@ -434,6 +437,90 @@ def weekend():
         json.dump(json.loads(json.dumps(out, default=float)), f, indent=0)
 
 
+def fuzz_cases(count=72, seed=20240601):
+    """Random configurations across the whole input space of run_monte_carlo (small runs)."""
+    rng = random.Random(seed)
+    teams = list(DEFAULT_DNF_RATES.keys())
+    cases = []
+    for k in range(count):
+        n = rng.choice([2, 3, 5, 8, 10, 12, 15, 18, 19, 20, 20, 20, 21, 22, 24])
+        drivers = [f'D{i:02d}' for i in range(n)]
+        laps = rng.choice([6, 9, 14, 22, 31, 44, 57, 66, 78, 90])
+        tc = {}
+        for name, info in TIRE_COMPOUNDS.items():
+            if rng.random() < 0.1:
+                continue                                    # missing compound: .get(compound, {}) defaults
+            d = {}
+            if rng.random() < 0.9:
+                d['pace_delta'] = round(info['pace_delta'] + rng.uniform(-0.4, 0.4), 3)
+            if rng.random() < 0.9:
+                d['deg_rate'] = rng.choice([info['deg_rate'], 0.02, 0.05, 0.1, 0.0])
+            if rng.random() < 0.9:
+                d['optimal_laps'] = rng.choice([info['optimal_laps'], 3, 8, 12, 20, 33])
+            tc[name] = d
+        heavy = rng.random() < 0.35
+        cfg = config_dict(
+            laps, rng.choice([18.0, 21.0, 24.5, 30.0]), rng.choice([0.2, 0.4, 0.6, 0.9, 1.5]),
+            sc=rng.choice([0.0, 0.01, 0.05, 0.3]) if heavy else 0.01,
+            vsc=rng.choice([0.0, 0.015, 0.08, 0.3]) if heavy else 0.015,
+            red=rng.choice([0.0, 0.002, 0.03, 0.2]) if heavy else 0.002,
+            tire_compounds=tc,
+            dnf_rates={t: DEFAULT_DNF_RATES[t] * rng.choice([1, 1, 5, 40]) for t in teams if rng.random() < 0.9},
+            driver_teams={d: rng.choice(teams) for d in drivers if rng.random() < 0.9},
+            drs_delta=rng.choice([0.0, 0.3, 0.55]), drs_zones=rng.randint(1, 4),
+            dirty_thr=rng.choice([2.0, 0.8, 3.5]), dirty_pen=rng.choice([0.5, 0.2, 1.0]))
+        style = rng.choice(['random', 'onehot', 'sparse', 'elo'])
+        if style == 'elo':
+            grid = elo_grid(drivers)
+        else:
+            grid = {}
+            perm = drivers[:]
+            rng.shuffle(perm)
+            for d in drivers:
+                if style == 'onehot':
+                    row = [1.0 if perm[s] == d else 0.0 for s in range(n)]
+                elif style == 'sparse':
+                    row = [rng.random() if rng.random() < 0.35 else 0.0 for _ in range(n)]
+                else:
+                    row = [rng.random() ** 3 for _ in range(n)]
+                grid[d] = row
+            if style == 'sparse' and n > 2:                 # an all-zero column: uniform fallback (Q18)
+                col = rng.randrange(n)
+                for d in drivers:
+                    grid[d][col] = 0.0
+        spread = rng.choice([0.02, 0.1, 0.4])
+        cases.append(dict(
+            name=f'F{k:02d}', n_sims=40, n_orders=40, n_trace=0, seed=rng.randrange(2 ** 32),
+            track_condition=rng.choice(['dry', 'dry', 'dry', 'damp', 'wet']), config=cfg, grid_probs=grid,
+            base_pace={d: 70.0 + 30.0 * rng.random() * 0 + 85.0 * 0 + 88.0 + spread * i + rng.uniform(-0.2, 0.2)
+                       for i, d in enumerate(drivers) if rng.random() < 0.92},
+            tire_deg={d: rng.choice([0.0, 0.01, 0.02, 0.03, 0.05, 0.050000000000000003, 0.07, 0.12, -0.01])
+                      for d in drivers if rng.random() < 0.9},
+            driver_variance={d: rng.choice([0.05, 0.15, 0.18, 0.3, 0.6]) for d in drivers if rng.random() < 0.9},
+            driver_dnf_rates=None if rng.random() < 0.25 else
+            {d: rng.choice([0.0, 0.0008, 0.004, 0.03, 0.2]) for d in drivers if rng.random() < 0.85},
+        ))
+    return cases
+
+
+def fuzz():
+    """Reference finishing orders for the random configurations: fuzz_cases.json + fuzz.npz."""
+    cases = fuzz_cases()
+    out = {}
+    for c in cases:
+        cfg = RaceConfig(**c['config'])
+        drivers = list(c['grid_probs'].keys())
+        sim = TracingSimulator(cfg, drivers, 0, c['n_orders'])
+        sim.run_monte_carlo(c['n_sims'], c['grid_probs'], c['base_pace'], c['tire_deg'], c['driver_variance'],
+                            c['driver_dnf_rates'], seed=c['seed'], track_condition=c['track_condition'])
+        out[c['name'] + '_orders'] = np.array(sim.orders, np.uint8)
+        out[c['name'] + '_grids'] = np.array(sim.grids, np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'fuzz.npz'), **out)
+    with open(os.path.join(HERE, 'fuzz_cases.json'), 'w') as f:
+        json.dump({c['name']: c for c in cases}, f, indent=0)
+    print(f'fuzz: {len(cases)} configurations', flush=True)
+
+
 def ref_stat(case, seeds, n_each):
     """Big-N reference histogram (one process per seed) for the statistical link."""
     import multiprocessing as mp
@@ -460,7 +547,7 @@ def _ref_stat_one(case, seed, n_each):
 
 
 def main():
-    what = sys.argv[1:] or ['cases', 'streams', 'grids', 'misc', 'weekend']
+    what = sys.argv[1:] or ['cases', 'streams', 'grids', 'misc', 'weekend', 'fuzz']
     cases = build_cases()
     if 'cases' in what:
         meta = dict(
@@ -483,6 +570,8 @@ def main():
         misc()
     if 'weekend' in what:
         weekend()
+    if 'fuzz' in what:
+        fuzz()
     if 'stat' in what:
         by = {c['name']: c for c in cases}
         ref_stat(by['S60'], list(range(101, 109)), 25000)
