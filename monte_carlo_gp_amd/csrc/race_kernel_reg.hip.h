@@ -207,6 +207,9 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
 #ifndef MCGP_MIN_WAVES
 #define MCGP_MIN_WAVES 2
 #endif
+#ifndef MCGP_PREPASS_BLOCKS
+#define MCGP_PREPASS_BLOCKS 2
+#endif
 template <int N>
 __global__ void __launch_bounds__(512, MCGP_MIN_WAVES)
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
@@ -462,27 +465,35 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             }
 
             // ---- this lap's draws, by driver pair: one Philox block = (dnf, noise) x 2 ----
-            // Two blocks per iteration: the two Philox chains interleave, and the four table look-ups
-            // of the inverse-normal transform go out as one batch.
+            // MCGP_PREPASS_BLOCKS blocks per iteration: their Philox chains interleave, and the table
+            // look-ups of the inverse-normal transform go out as one batch.
 #pragma unroll 1
             for (int rep = 0; rep < ((MCGP_DUP & 2) ? 2 : 1); ++rep)
 #pragma unroll 1
-            for (int b = 0; b < (N + 1) / 2; b += 2) {
-                uint32_t w0, w1, w2, w3, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-                philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (uint32_t)b, seed_lo, seed_hi, w0, w1, w2, w3);
-                const bool second = b + 1 < (N + 1) / 2;
-                if (second)
-                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (uint32_t)(b + 1), seed_lo, seed_hi, x0, x1, x2, x3);
-                const int d0 = 2 * b, d1 = 2 * b + 1, d2 = 2 * b + 2, d3 = 2 * b + 3;
-                const float z0 = normal_from_u32(w1, t_norm), z1 = normal_from_u32(w3, t_norm);
-                const float z2 = normal_from_u32(x1, t_norm), z3 = normal_from_u32(x3, t_norm);
-                const unsigned long long q0 = t_dnf[d0], q1 = t_dnf[d1 < N ? d1 : 0];
-                const unsigned long long q2 = t_dnf[d2 < N ? d2 : 0], q3 = t_dnf[d3 < N ? d3 : 0];
-                ZED(d0) = ((uint64_t)w0 < q0) ? kNaN : z0;
-                if (d1 < N) ZED(d1) = ((uint64_t)w2 < q1) ? kNaN : z1;
-                if (second) {
-                    ZED(d2) = ((uint64_t)x0 < q2) ? kNaN : z2;
-                    if (d3 < N) ZED(d3) = ((uint64_t)x2 < q3) ? kNaN : z3;
+            for (int b0 = 0; b0 < (N + 1) / 2; b0 += MCGP_PREPASS_BLOCKS) {
+                uint32_t w[MCGP_PREPASS_BLOCKS][4];
+#pragma unroll
+                for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
+                    w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0u;
+                    if (b0 + j < (N + 1) / 2)
+                        philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (uint32_t)(b0 + j), seed_lo, seed_hi,
+                                      w[j][0], w[j][1], w[j][2], w[j][3]);
+                }
+                float z[MCGP_PREPASS_BLOCKS][2];
+                unsigned long long q[MCGP_PREPASS_BLOCKS][2];
+#pragma unroll
+                for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
+                    const int d0 = 2 * (b0 + j), d1 = d0 + 1;
+                    z[j][0] = normal_from_u32(w[j][1], t_norm);
+                    z[j][1] = normal_from_u32(w[j][3], t_norm);
+                    q[j][0] = t_dnf[d0 < N ? d0 : 0];
+                    q[j][1] = t_dnf[d1 < N ? d1 : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
+                    const int d0 = 2 * (b0 + j), d1 = d0 + 1;
+                    if (d0 < N) ZED(d0) = ((uint64_t)w[j][0] < q[j][0]) ? kNaN : z[j][0];
+                    if (d1 < N) ZED(d1) = ((uint64_t)w[j][2] < q[j][1]) ? kNaN : z[j][1];
                 }
             }
 
