@@ -503,9 +503,39 @@ def fuzz_cases(count=72, seed=20240601):
     return cases
 
 
+def extreme_cases():
+    """Corner configurations: certain events, everybody retiring, every pair attempting, 1-2 lap races."""
+    out = []
+
+    def mk(name, laps, **over):
+        c = canonical_case(name, laps, 'Bahrain', 30, 0, seed=over.pop('seed', 3))
+        c['n_orders'] = 30
+        for k, v in over.items():
+            if k in c['config']:
+                c['config'][k] = v
+            else:
+                c[k] = v
+        return c
+    out.append(mk('X_onelap', 1))
+    out.append(mk('X_twolaps', 2))
+    out.append(mk('X_always_sc', 12, sc_probability=1.0, red_flag_probability=0.0))
+    out.append(mk('X_always_vsc', 12, sc_probability=0.0, red_flag_probability=0.0, vsc_probability=1.0))
+    out.append(mk('X_always_red', 40, red_flag_probability=1.0))
+    out.append(mk('X_all_attempt', 15, overtake_delta=-50.0, drs_delta=5.0))
+    out.append(mk('X_never_attempt', 15, overtake_delta=1e9))
+    allout = mk('X_all_out_lap1', 10, dnf_rates={t: 0.25 for t in DEFAULT_DNF_RATES})
+    out.append(allout)
+    out.append(mk('X_all_out_lap2', 10, driver_dnf_rates={d: 1.0 for d in DRIVER_TEAMS}))
+    out.append(mk('X_half_out', 20, driver_dnf_rates={d: 0.5 for d in DRIVER_TEAMS}, sc_probability=0.5))
+    out.append(mk('X_no_noise', 25, driver_variance={d: 0.0 for d in DRIVER_TEAMS},
+                  base_pace={d: 90.0 for d in DRIVER_TEAMS}))
+    out.append(mk('X_pit_every_lap', 30, tire_compounds={k: dict(v, optimal_laps=0) for k, v in TIRE_COMPOUNDS.items()}))
+    return out
+
+
 def fuzz():
     """Reference finishing orders for the random configurations: fuzz_cases.json + fuzz.npz."""
-    cases = fuzz_cases()
+    cases = fuzz_cases() + extreme_cases()
     out = {}
     for c in cases:
         cfg = RaceConfig(**c['config'])

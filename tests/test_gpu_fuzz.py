@@ -1,4 +1,4 @@
-"""HIP vs oracle (Philox) on the 72 random configurations of tests/golden/fuzz_cases.json
+"""HIP vs oracle (Philox) on the 84 configurations (72 random + 12 corner cases) of tests/golden/fuzz_cases.json
 (the same configurations on which the oracle's MT back-end is pinned to the reference)."""
 import json
 
