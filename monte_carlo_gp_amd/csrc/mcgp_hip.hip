@@ -42,7 +42,8 @@ int fail(int code, const std::string &msg)
 #ifdef MCGP_ONLY_N20      // diagnostic builds (tools/ablate.sh)
 #define MCGP_REG_SIZES(X) X(20)
 #else
-#define MCGP_REG_SIZES(X) X(10) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+#define MCGP_REG_SIZES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) \
+    X(18) X(19) X(20) X(21) X(22) X(23) X(24)
 #endif
 
 constexpr int kParamSlots = 4;

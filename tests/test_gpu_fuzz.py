@@ -11,18 +11,26 @@ from helpers import product_run
 pytestmark = pytest.mark.gpu
 
 
-def test_fuzzed_configurations_match_oracle(require_gpu):
-    with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
-        cases = json.load(f)
+def _check(cases, names, n_sims):
+    from monte_carlo_gp_amd import _native as N
     kernels = set()
-    for name, c in cases.items():
-        n_sims = 1500
+    for name in names:
+        c = cases[name]
         ref = O.Problem(c).run(n_sims, rng=O.RNG_PHILOX, seed=c['seed'], want_orders=True)
         hist, _, orders = product_run(c, n_sims, c['seed'], orders=True)
         bad = np.nonzero((orders != ref['orders']).any(axis=1))[0]
         assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
         assert np.array_equal(hist, ref['hist']), name
-        from monte_carlo_gp_amd import _native as N
         kernels.add(N.lib().mcgp_last_kernel_name(0).decode())
-    # both kernel families were exercised
-    assert 'mcgp::race_kernel' in kernels and any(k.startswith('mcgp::race_kernel_reg<') for k in kernels)
+    return kernels
+
+
+def test_fuzzed_configurations_match_oracle(require_gpu, monkeypatch):
+    with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
+        cases = json.load(f)
+    names = list(cases)
+    kernels = _check(cases, names, 1500)
+    assert all(k.startswith('mcgp::race_kernel_reg<') for k in kernels) and len(kernels) >= 10
+    # the generic LDS kernel on every third configuration
+    monkeypatch.setenv('MCGP_FORCE_GENERIC', '1')
+    assert _check(cases, names[::3], 1000) == {'mcgp::race_kernel'}
