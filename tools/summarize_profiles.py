@@ -93,6 +93,12 @@ def main():
                      ('SQ_WAIT_ANY', 'wave-cycles waiting (s_waitcnt)'), ('SQ_WAIT_INST_ANY', 'wave-cycles stalled on issue')):
         lines.append(f'| {label} / SQ_WAVE_CYCLES | {g(k) / wc:.2f} |')
     lines.append(f'| LDS bank-conflict cycles / LDS active cycles | {g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"):.3f} |')
+    if 'GRBM_GUI_ACTIVE' in allc:
+        gui = g('GRBM_GUI_ACTIVE') / 8          # rocprofv3 sums the 8 XCDs
+        lines.append(f'| **VALUBusy** = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) (gfx9 derived-metric formula) | **{400 * g("SQ_ACTIVE_INST_VALU") / 1024 / gui:.1f} %** |')
+        lines.append(f'| resident waves per SIMD, time average (4 x SQ_WAVE_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8)) | {4 * wc / 1024 / gui:.2f} |')
+        if kernel_ms:
+            lines.append(f'| shader clock (GRBM_GUI_ACTIVE / 8 / kernel time) | {gui / (kernel_ms * 1e-3) / 1e9:.2f} GHz |')
     if kernel_ms:
         simd_cycles = 1024 * kernel_ms * 1e-3 * 2.4e9
         lines.append(f'| VALU instructions / (1024 SIMDs x kernel time x 2.4 GHz) | {g("SQ_INSTS_VALU") / simd_cycles:.3f} per SIMD-cycle |')
