@@ -56,6 +56,13 @@ def main():
         c, m = counters(tag, sub)
         allc.update(c)
         meta = m or meta
+    stored = os.path.join(out_dir, f'{tag}_counters.json')
+    if not allc and os.path.exists(stored):
+        # raw rocprofv3 output (gpurun_out/, scratch) is gone: re-render from the tracked counters file
+        with open(stored) as f:
+            old = json.load(f)
+        allc, meta, kernel_ms = old['counters'], old['kernel'], old['kernel_ms_avg']
+        calls = old.get('calls', 6)
     traffic = None
     if 'FETCH_SIZE' in allc and 'WRITE_SIZE' in allc:
         traffic = dict(fetch_bytes_raw=allc['FETCH_SIZE'] * 1024, write_bytes=allc['WRITE_SIZE'] * 1024,
@@ -66,7 +73,7 @@ def main():
             json.dump(dict(workload='S60', sims_per_launch=int(sims), source=f'{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE',
                            **traffic), f, indent=1)
     with open(os.path.join(out_dir, f'{tag}_counters.json'), 'w') as f:
-        json.dump(dict(kernel=meta, kernel_ms_avg=kernel_ms, sims_per_launch=sims, counters=allc, traffic=traffic),
+        json.dump(dict(kernel=meta, kernel_ms_avg=kernel_ms, calls=calls if kernel_ms else None, sims_per_launch=sims, counters=allc, traffic=traffic),
                   f, indent=1)
     waves = sims / 64
     g = lambda k: allc.get(k, float('nan'))
@@ -103,6 +110,8 @@ def main():
         simd_cycles = 1024 * kernel_ms * 1e-3 * 2.4e9
         lines.append(f'| VALU instructions / (1024 SIMDs x kernel time x 2.4 GHz) | {g("SQ_INSTS_VALU") / simd_cycles:.3f} per SIMD-cycle |')
     abl = os.path.join(ROOT, 'gpurun_out', 'ablate.txt')
+    if not os.path.exists(abl):
+        abl = os.path.join(out_dir, f'{tag}_ablate.txt')
     if os.path.exists(abl):
         vals = collections.defaultdict(list)
         for line in open(abl):
@@ -110,7 +119,8 @@ def main():
             if v:
                 vals[k].append(float(v))
         if 'DUP=0' in vals:
-            shutil.copy(abl, os.path.join(out_dir, f'{tag}_ablate.txt'))
+            if os.path.abspath(abl) != os.path.abspath(os.path.join(out_dir, f'{tag}_ablate.txt')):
+                shutil.copy(abl, os.path.join(out_dir, f'{tag}_ablate.txt'))
             base = sum(vals['DUP=0']) / len(vals['DUP=0'])
             names = {'DUP=1': 'sorting network after the lap step (run twice)', 'DUP=2': 'per-lap RNG pre-pass: 10 Philox blocks + 20 deviates (run twice)',
                      'DUP=4': '_update_positions (run twice)', 'DUP=8': 'one extra transposition re-sort per successful overtake pass',
