@@ -110,8 +110,8 @@ def main():
         simd_cycles = 1024 * kernel_ms * 1e-3 * 2.4e9
         lines.append(f'| VALU instructions / (1024 SIMDs x kernel time x 2.4 GHz) | {g("SQ_INSTS_VALU") / simd_cycles:.3f} per SIMD-cycle |')
     abl = os.path.join(ROOT, 'gpurun_out', 'ablate.txt')
-    if not os.path.exists(abl):
-        abl = os.path.join(out_dir, f'{tag}_ablate.txt')
+    if not os.path.exists(abl) or 'DUP=0' not in open(abl).read():
+        abl = os.path.join(out_dir, f'{tag}_ablate.txt')      # the tracked copy of the DUP/SKIP run
     if os.path.exists(abl):
         vals = collections.defaultdict(list)
         for line in open(abl):
