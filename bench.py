@@ -179,13 +179,15 @@ def main():
         # VALU issue roofline (the binding resource): wave-level VALU instructions per launch from the PMC pass
         # kept under profiles/ (a property of the workload, not of the box) over the live kernel time;
         # peak = 1024 SIMDs x 2.4 GHz / 2 cycles per 32-bit wave64 instruction (MI355X_MICROARCH.md)
-        valu_frac = valu_insts = None
+        valu_frac = valu_insts = valu_busy = None
         try:
             with open(os.path.join(ROOT, 'profiles', 'r1_counters.json')) as f:
                 pc = json.load(f)
             if args.workload == 'S60' and pc.get('sims_per_launch') == per_gpu:
                 valu_insts = pc['counters']['SQ_INSTS_VALU']
                 valu_frac = valu_insts / (kavg_ms * 1e-3) / (1024 * 2.4e9 / 2)
+                # VALUBusy of the profiled run (gfx9 formula: 4 x SQ_ACTIVE_INST_VALU / SIMDs / busy cycles)
+                valu_busy = 4 * pc['counters']['SQ_ACTIVE_INST_VALU'] / 1024 / (pc['counters']['GRBM_GUI_ACTIVE'] / 8)
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -211,6 +213,7 @@ def main():
             'valu': {'car_laps_per_s': per_gpu * n * L / (kavg_ms * 1e-3),
                      'sims_per_s_kernel_only': per_gpu / (kavg_ms * 1e-3),
                      'valu_insts_per_launch': valu_insts, 'valu_issue_frac_of_peak': valu_frac,
+                     'valu_busy_profiled': valu_busy,
                      'launch': {'grid': g.value, 'block': b.value, 'lds_bytes': lds.value}},
             'win_probability_top3': {drivers[i]: float(hist[i, 0]) / total_sims for i in np.argsort(-hist[:, 0])[:3]},
         }
