@@ -37,6 +37,7 @@ import numpy as np  # noqa: E402
 SIMS_PER_STEP = 10_000_000
 ALGORITHMIC_BYTES_PER_SIM = 20          # the n x u8 finishing order, SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TINST = 1024 * 2.4e9 / 2 / 1e12   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 
 
 def load_workload(name):
@@ -45,9 +46,31 @@ def load_workload(name):
     return meta['cases'][name], meta['set_pop']
 
 
-def cpu_baseline(case_name, seconds=12.0):
-    """Oracle (kind "port"), MT back-end, one core, bounded sample of the same workload."""
+def host_info():
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return dict(cpu_model=model, nproc=os.cpu_count() or 1, usable_cores=usable)
+
+
+def cpu_baseline(case_name, seconds=12.0, all_core_seconds=8.0):
+    """The CPU oracle timed on this box's host cores, bounded samples of the same workload:
+      * value / cores=1: Mersenne-Twister back-end, one thread -- the reference-equivalent path (kind "port");
+      * all_cores: Philox back-end (the arithmetic the GPU kernel runs, draw for draw), one thread per usable
+        core over disjoint sim_offset ranges (ctypes releases the GIL)."""
     import oracle_py as O
+    from concurrent.futures import ThreadPoolExecutor
+    info = host_info()
     P = O.Problem(O.load_case(case_name))
     mt = O.MTState(42)
     P.run(200, rng=O.RNG_MT, mt=mt)            # warm-up / page-in
@@ -59,8 +82,56 @@ def cpu_baseline(case_name, seconds=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds:
             break
-    return dict(value=done / dt, unit='race-simulations/s', cores=1, kind='port',
-                sample=f'{done} simulations of {case_name} (MT back-end, reference draw order), {dt:.1f} s, 1 thread')
+    out = dict(value=done / dt, unit='race-simulations/s', cores=1, kind='port',
+               sample=f'{done} simulations of {case_name} (MT back-end, reference draw order), {dt:.1f} s, 1 thread',
+               **info,
+               reference_python_sims_per_s={'S60': 180, 'S78': 139,
+                                            'note': 'the pure-Python reference itself, 1 core of the build container '
+                                                    '(SURVEY.md section 6 probe); it cannot travel to the GPU box'})
+    # all-core leg: calibrate one thread for ~1 s, then size the sample for all_core_seconds on every core
+    t0 = time.perf_counter()
+    P.run(chunk, rng=O.RNG_PHILOX, seed=42)
+    one = chunk / (time.perf_counter() - t0)
+    cores = info['usable_cores']
+    per_thread = max(chunk, int(one * all_core_seconds / chunk) * chunk)
+    problems = [O.Problem(O.load_case(case_name)) for _ in range(cores)]
+
+    def work(i):
+        left, off = per_thread, i * per_thread
+        while left > 0:
+            problems[i].run(chunk, rng=O.RNG_PHILOX, seed=42, sim_offset=off)
+            left -= chunk
+            off += chunk
+        return per_thread
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    out['all_cores'] = dict(value=total / dt, unit='race-simulations/s', cores=cores, kind='port',
+                            sample=f'{total} simulations of {case_name} (Philox back-end), {dt:.1f} s, {cores} threads',
+                            one_thread_philox=one)
+    return out
+
+
+def profiled_counters(workload, per_gpu, lib_overridden):
+    """PMC-derived figures kept under profiles/ (rocprofv3 --pmc passes, tools/summarize_profiles.py), quoted
+    ONLY when the file is stamped with the hash of the kernel sources the loaded library was built from."""
+    from monte_carlo_gp_amd import _native as N
+    path = os.path.join(ROOT, 'profiles', 'r2_counters.json')
+    if lib_overridden:
+        return None, 'MCGP_LIB is set: counters under profiles/ belong to the product build'
+    try:
+        with open(path) as f:
+            pc = json.load(f)
+    except (OSError, ValueError) as e:
+        return None, f'no usable {os.path.relpath(path, ROOT)}: {e}'
+    if pc.get('source_hash') != N.source_hash():
+        return None, (f"profiles/r2_counters.json was taken from sources {pc.get('source_hash')}, "
+                      f'the loaded library is built from {N.source_hash()}: re-profile')
+    w = pc.get('workloads', {}).get(workload)
+    if not w or w.get('sims_per_launch') != per_gpu:
+        return None, f'profiles/r2_counters.json has no {workload} entry at {per_gpu} simulations per launch'
+    return w, None
 
 
 def main():
@@ -71,6 +142,7 @@ def main():
     ap.add_argument('--workload', default='S60')
     ap.add_argument('--sims-per-step', type=int, default=SIMS_PER_STEP)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the S78 and orders-mode side measurements')
     args = ap.parse_args()
 
     import torch
@@ -83,6 +155,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    lib = N.lib()                            # builds once per node (flock) BEFORE anything touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     # Rehearsal knobs (one-GPU box): MCGP_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and reduces over
@@ -97,38 +170,8 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
-
-    case, set_pop = load_workload(args.workload)
-    cfg = RaceConfig(**case['config'])
-    drivers = list(case['grid_probs'].keys())
-    n = len(drivers)
-    L = cfg.total_laps
-    prob = _Problem(cfg, drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
-                    case['driver_dnf_rates'], case['track_condition'], set_pop)
-    grid = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
-    seed = case['seed']
-    lib = N.lib()
     per_gpu = args.sims_per_step
-
-    d_hist = torch.zeros(n * n, dtype=torch.int64, device=dev)       # running total (all ranks, all steps)
-    d_step = torch.zeros(n * n, dtype=torch.int64, device=dev)       # this step's histogram
     stream = torch.cuda.current_stream(dev)
-
-    def step(index):
-        # global simulation ids: [index * world * per_gpu, (index + 1) * world * per_gpu), split by rank
-        offset = (index * world + rank) * per_gpu
-        d_step.zero_()
-        N.check(lib.mcgp_run_device(C.byref(prob.cfg), C.byref(prob.drv), _dptr(grid), n, per_gpu, offset,
-                                    seed, local_rank, C.c_void_p(stream.cuda_stream),
-                                    C.c_void_p(d_step.data_ptr()), None))
-        if world > 1:
-            if share:
-                h = d_step.cpu()
-                dist.all_reduce(h)
-                d_step.copy_(h)
-            else:
-                dist.all_reduce(d_step)        # RCCL over xGMI: 400 x int64, the path's only exchange
-        d_hist.add_(d_step)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -136,87 +179,132 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for w in range(args.warmup):
-        step(w)
-    sync()
-    d_hist.zero_()
-    kernel_ms = []
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-        ms = C.c_float()
-        # hipEvents recorded on the launch stream around the kernel (read after the step's work is queued;
-        # the query synchronises on the stop event only)
-        N.check(lib.mcgp_last_kernel_ms(local_rank, C.byref(ms)))
-        kernel_ms.append(ms.value)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_workload(name, steps, warmup, with_orders=False):
+        """`warmup` untimed steps, then exactly `steps` timed steps between barrier + synchronize pairs."""
+        case, set_pop = load_workload(name)
+        cfg = RaceConfig(**case['config'])
+        drivers = list(case['grid_probs'].keys())
+        n, L = len(drivers), cfg.total_laps
+        prob = _Problem(cfg, drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
+                        case['driver_dnf_rates'], case['track_condition'], set_pop)
+        grid = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+        seed = case['seed']
+        d_hist = torch.zeros(n * n, dtype=torch.int64, device=dev)       # running total (all ranks, all steps)
+        d_step = torch.zeros(n * n, dtype=torch.int64, device=dev)       # this step's histogram
+        d_orders = torch.empty(per_gpu * n, dtype=torch.uint8, device=dev) if with_orders else None
 
-    total_sims = per_gpu * world * args.steps
-    hist = d_hist.cpu().numpy().reshape(n, n)
-    if rank == 0:
-        if not os.environ.get('MCGP_BENCH_NOCHECK'):      # diagnostic ablation builds produce wrong results on purpose
-            assert int(hist.sum()) == total_sims * n, (int(hist.sum()), total_sims * n)
-            assert (hist.sum(axis=1) == total_sims).all() and (hist.sum(axis=0) == total_sims).all()
-        kavg_ms = float(np.mean(kernel_ms))
+        def step(index):
+            # global simulation ids: [index * world * per_gpu, (index + 1) * world * per_gpu), split by rank
+            offset = (index * world + rank) * per_gpu
+            d_step.zero_()
+            N.check(lib.mcgp_run_device(C.byref(prob.cfg), C.byref(prob.drv), _dptr(grid), n, per_gpu, offset,
+                                        seed, local_rank, C.c_void_p(stream.cuda_stream),
+                                        C.c_void_p(d_step.data_ptr()),
+                                        C.c_void_p(d_orders.data_ptr()) if with_orders else None))
+            if world > 1:
+                if share:
+                    h = d_step.cpu()
+                    dist.all_reduce(h)
+                    d_step.copy_(h)
+                else:
+                    dist.all_reduce(d_step)        # RCCL over xGMI: 400 x int64, the path's only exchange
+            d_hist.add_(d_step)
+
+        for w in range(warmup):
+            step(w)
+        sync()
+        d_hist.zero_()
+        kernel_ms = []
+        sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k)
+            ms = C.c_float()
+            # hipEvents recorded by the library on the launch stream around the kernel (read after the step's
+            # work is queued; the query synchronises on the stop event only)
+            N.check(lib.mcgp_last_kernel_ms(local_rank, C.byref(ms)))
+            kernel_ms.append(ms.value)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        total = per_gpu * world * steps
+        hist = d_hist.cpu().numpy().reshape(n, n)
+        if rank == 0 and not os.environ.get('MCGP_BENCH_NOCHECK'):    # diagnostic ablation builds are wrong on purpose
+            assert int(hist.sum()) == total * n, (int(hist.sum()), total * n)
+            assert (hist.sum(axis=1) == total).all() and (hist.sum(axis=0) == total).all()
+        if with_orders and rank == 0:
+            o = d_orders[:n * 4096].cpu().numpy().reshape(4096, n)
+            assert (np.sort(o, axis=1) == np.arange(n)).all(), 'orders rows are not permutations'
         g, b, lds = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib.mcgp_last_launch_info(local_rank, C.byref(g), C.byref(b), C.byref(lds))
+        return dict(name=name, n=n, L=L, seed=seed, drivers=drivers, elapsed=elapsed, total=total, hist=hist,
+                    kernel_ms=float(np.mean(kernel_ms)), kernel=lib.mcgp_last_kernel_name(local_rank).decode(),
+                    launch={'grid': g.value, 'block': b.value, 'lds_bytes': lds.value})
+
+    r = run_workload(args.workload, args.steps, args.warmup)
+    if rank == 0:
+        n, L, kavg_ms, hist = r['n'], r['L'], r['kernel_ms'], r['hist']
         achieved = per_gpu * ALGORITHMIC_BYTES_PER_SIM / (kavg_ms * 1e-3) / 1e9
-        kernel_name = lib.mcgp_last_kernel_name(local_rank).decode()
-        traffic = None      # HBM bytes per launch from the PMC passes kept under profiles/ (same workload)
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-                t = json.load(f)
-            if t.get('workload') == args.workload and t.get('sims_per_launch') == per_gpu:
-                traffic = t['hbm_bytes_per_launch']
-        except (OSError, ValueError, KeyError):
-            pass
-        # VALU issue roofline (the binding resource): wave-level VALU instructions per launch from the PMC pass
-        # kept under profiles/ (a property of the workload, not of the box) over the live kernel time;
-        # peak = 1024 SIMDs x 2.4 GHz / 2 cycles per 32-bit wave64 instruction (MI355X_MICROARCH.md)
-        valu_frac = valu_insts = valu_busy = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r1_counters.json')) as f:
-                pc = json.load(f)
-            if args.workload == 'S60' and pc.get('sims_per_launch') == per_gpu:
-                valu_insts = pc['counters']['SQ_INSTS_VALU']
-                valu_frac = valu_insts / (kavg_ms * 1e-3) / (1024 * 2.4e9 / 2)
-                # VALUBusy of the profiled run (gfx9 formula: 4 x SQ_ACTIVE_INST_VALU / SIMDs / busy cycles)
-                valu_busy = 4 * pc['counters']['SQ_ACTIVE_INST_VALU'] / 1024 / (pc['counters']['GRBM_GUI_ACTIVE'] / 8)
-        except (OSError, ValueError, KeyError):
-            pass
+        pc, why_not = profiled_counters(args.workload, per_gpu, bool(os.environ.get('MCGP_LIB')))
+        traffic = valu = None
+        if pc:
+            traffic = pc.get('hbm_bytes_per_launch')
+            insts = pc['SQ_INSTS_VALU']
+            # VALU issue roofline (the binding resource): wave-level VALU instructions per launch (a property of
+            # the workload and the code, stamped with the source hash) over the LIVE kernel time; peak = 1024
+            # SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cycles)
+            valu = {'bound': 'valu-issue', 'achieved': insts / (kavg_ms * 1e-3) / 1e12, 'peak': VALU_PEAK_TINST,
+                    'unit': 'T wave-instructions/s', 'frac': insts / (kavg_ms * 1e-3) / 1e12 / VALU_PEAK_TINST,
+                    'valu_insts_per_launch': insts, 'active_lane_ratio': pc.get('active_lane_ratio'),
+                    'valu_busy_profiled': pc.get('valu_busy'), 'source_hash': pc.get('source_hash_checked')}
         out = {
             'metric': f'race-simulations/sec ({n} drivers, {L} laps)',
-            'value': total_sims / elapsed,
+            'value': r['total'] / r['elapsed'],
             'unit': 'race-simulations/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
+            'ms_per_step': r['elapsed'] / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f64',
+            'dtype_note': 'race state and every comparison in IEEE binary64 (as the reference); random deviates carry '
+                          '32 bits: uniforms w/2^32, normals from a binary32 piecewise-cubic inverse CDF (|err| <= 4.8e-7)',
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {n} drivers, {L} laps, {per_gpu} simulations per GPU per step, '
-                                   f'fixed Elo grid, seed {seed}',
+                                   f'fixed Elo grid, seed {r["seed"]}',
                        'sims_per_gpu_per_step': per_gpu, 'parallelism': f'sims sharded over {world} GPU(s)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': kernel_name, 'kernel_ms_avg': kavg_ms,
-                         'note': 'path is VALU/LDS-issue bound, not HBM bound: 20 algorithmic bytes per simulation'},
+                         'kernel': r['kernel'], 'kernel_ms_avg': kavg_ms,
+                         'note': 'nominal: 20 algorithmic bytes per simulation (the finishing order) over the kernel time; '
+                                 'in this histogram-only mode they are not written (3.2 KB per launch is). The path is '
+                                 'VALU-issue bound, not HBM bound: see roofline_valu; orders_mode times the run that '
+                                 'does write the 20 B per simulation',
+                         'counters_note': why_not},
+            'roofline_valu': valu,
             'valu': {'car_laps_per_s': per_gpu * n * L / (kavg_ms * 1e-3),
-                     'sims_per_s_kernel_only': per_gpu / (kavg_ms * 1e-3),
-                     'valu_insts_per_launch': valu_insts, 'valu_issue_frac_of_peak': valu_frac,
-                     'valu_busy_profiled': valu_busy,
-                     'launch': {'grid': g.value, 'block': b.value, 'lds_bytes': lds.value}},
-            'win_probability_top3': {drivers[i]: float(hist[i, 0]) / total_sims for i in np.argsort(-hist[:, 0])[:3]},
+                     'sims_per_s_kernel_only': per_gpu / (kavg_ms * 1e-3), 'launch': r['launch']},
+            'win_probability_top3': {r['drivers'][i]: float(hist[i, 0]) / r['total'] for i in np.argsort(-hist[:, 0])[:3]},
         }
+    if world == 1 and not args.no_extras:
+        # side measurements in the same run (not part of `value`): BASELINE configs[2] and the orders-writing mode
+        w78 = run_workload('S78', 3, 1)
+        wo = run_workload(args.workload, 3, 1, with_orders=True)
+        out['workloads'] = {'S78': {
+            'metric': f"race-simulations/sec ({w78['n']} drivers, {w78['L']} laps; Monaco parameters, BASELINE configs[2])",
+            'value': w78['total'] / w78['elapsed'], 'steps': 3, 'kernel_ms_avg': w78['kernel_ms'],
+            'car_laps_per_s': per_gpu * w78['n'] * w78['L'] / (w78['kernel_ms'] * 1e-3)}}
+        bytes_written = per_gpu * wo['n']
+        out['orders_mode'] = {'value': wo['total'] / wo['elapsed'], 'unit': 'race-simulations/s', 'steps': 3,
+                              'kernel_ms_avg': wo['kernel_ms'], 'bytes_per_launch': bytes_written,
+                              'write_gb_per_s': bytes_written / (wo['kernel_ms'] * 1e-3) / 1e9,
+                              'frac_of_hbm_peak': bytes_written / (wo['kernel_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -106,7 +106,10 @@ int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
  * (a hipStream_t, NULL = the device's default stream): d_hist (n*n uint64, device,
  * accumulated) and optional d_orders (n_sims*n uint8, device).  Used by the
  * multi-GPU path (RCCL all-reduce of d_hist) and by bench.py.  The small
- * parameter block is uploaded on the same stream before the launch. */
+ * parameter block is uploaded on the same stream before the launch; a block cached
+ * from an earlier call on ANOTHER stream is re-used only behind an event wait on
+ * that upload.  Runs of 2^32 simulations or more are split into several launches
+ * on the stream (the per-block histogram counts in 32 bits). */
 int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs,
                         uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
                         int32_t device, void *stream, uint64_t *d_hist, uint8_t *d_orders);
@@ -119,10 +122,12 @@ int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, cons
                            uint32_t n, uint64_t sim_id, uint64_t seed, int32_t device,
                            uint8_t *order_out);
 
-/* Measurement hooks (bench.py): duration in ms of the most recent race kernel
- * launched by this thread's last mcgp_run / mcgp_run_device on `device`, from
- * hipEvents recorded on the launch stream (synchronises on the stop event);
- * and the launch geometry that call used. */
+/* Measurement hooks (bench.py): duration in ms of the race kernel(s) of the MOST
+ * RECENT mcgp_run / mcgp_run_device / mcgp_simulate_race call on `device` -- by any
+ * thread: the timing events belong to the device context, not to the caller -- from
+ * hipEvents recorded on that call's launch stream (synchronises on the stop event);
+ * and the launch geometry that call used.  Meaningful when one thread drives the
+ * device, which is how bench.py uses it. */
 int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out);
 int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads,
                               uint32_t *lds_bytes);

@@ -44,14 +44,48 @@ class McgpDrivers(C.Structure):
                 ('base_pace', 'tire_deg', 'tire_deg_pit', 'variance', 'team_dnf', 'lap_dnf')]
 
 
-def build(force=False):
-    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ('mcgp_hip.hip', 'reg_inst.hip', 'race_common.hip.h', 'race_kernel.hip.h', 'race_kernel_reg.hip.h', 'normal_table.h', 'Makefile')]
+def _sources():
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+            if f.endswith(('.hip', '.h')) or f == 'Makefile']
     srcs.append(os.path.join(os.path.dirname(_PKG), 'include', 'mcgp.h'))
-    stale = (not os.path.exists(LIB_PATH)
-             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
-    if force or stale:
-        subprocess.check_call(['make', '-C', CSRC, '-s', '-B'])
+    return srcs
+
+
+def _stale():
+    return (not os.path.exists(LIB_PATH)
+            or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in _sources()))
+
+
+def source_hash():
+    """sha256 over the kernel sources and the Makefile (sorted by name): ties a profile under profiles/ to
+    the code it was taken from (bench.py quotes counters only when this matches)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(_sources(), key=os.path.basename):
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU).
+
+    One builder per node: an exclusive flock serialises the ranks of a torch.distributed.run launch (the
+    first one in builds, the others find the library up to date), make relinks through a temporary file
+    renamed into place, and an up-to-date tree is a no-op.  Runs before any HIP call of this process."""
+    if not (force or _stale()):
+        return LIB_PATH
+    import fcntl
+    os.makedirs(os.path.join(CSRC, 'build'), exist_ok=True)
+    with open(os.path.join(CSRC, 'build', '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _stale():
+                subprocess.check_call(['make', '-C', CSRC, '-s'] + (['-B'] if force else []))
+                os.utime(LIB_PATH)        # newer than every source even if make found nothing to do
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -81,10 +81,65 @@ def load_results(season: int) -> list:
         return json.load(f)['races']
 
 
+def _update_known_pairs(elo, key: str, drivers: list, ranked: list) -> None:
+    """The reference's all-pairs Elo update (src/elo.py:45-122: deltas from the ratings BEFORE the event,
+    K (actual - expected) / (n - 1) per pair) restricted to the pairs whose outcome the fixture knows:
+    every driver in `ranked` beat every driver after it in `ranked` and every driver not in it."""
+    n = len(drivers)
+    before = {d: elo.ratings[d][key] for d in drivers}
+    delta = {d: 0.0 for d in drivers}
+    for i, a in enumerate(ranked):
+        beaten = ranked[i + 1:] + [d for d in drivers if d not in ranked]
+        for b in beaten:
+            delta[a] += elo.k * (1.0 - elo.expected_score(before[a], before[b])) / (n - 1)
+            delta[b] += elo.k * (0.0 - elo.expected_score(before[b], before[a])) / (n - 1)
+    for d in drivers:
+        elo.ratings[d][key] = before[d] + delta[d]
+
+
+def season_fixtures(season: int, entries: list) -> list:
+    """One race fixture per race of the season: the synthetic weekend with the Elo quali ratings the
+    EARLIER races of that season produced, in calendar order.
+
+    Mirrors the loop of reference validation.py:179-205: predict race k, then update the Elo system with
+    race k's outcome before predicting race k+1 (K grows with the race index, reference src/elo.py:13-38).
+    The outcome fixture only holds pole, winner and podium, so the update covers the pairs it knows
+    (_update_known_pairs): the pole sitter out-qualified everybody; the podium finishers beat everybody
+    behind them.  (As written, the reference's own update at validation.py:195-199 passes bare driver codes
+    where update_*_ratings expects (driver, value) pairs; the ValueError is swallowed by its `except
+    Exception: pass`, so its Elo never moves during a backtest.  This sweep applies the update that loop
+    intends.)  Deterministic and cheap (24 x O(n^2) on the host): every rank builds the whole list, then
+    races shard over ranks.
+    """
+    from .elo import F1EloSystem
+    base = synthetic_fixture()
+    drivers = base['drivers']
+    elo = F1EloSystem()
+    for d in drivers:
+        elo.ratings[d] = {'quali': base['quali_ratings'][d], 'race': base['quali_ratings'][d]}
+    out = []
+    total = len(entries)
+    for idx, entry in enumerate(entries):
+        out.append(dict(base, quali_ratings={d: elo.ratings[d]['quali'] for d in drivers},
+                        race_ratings={d: elo.ratings[d]['race'] for d in drivers}, race_index=idx))
+        elo.set_recency_weight(0, idx, total)
+        if entry.get('pole') in elo.ratings:
+            _update_known_pairs(elo, 'quali', drivers, [entry['pole']])
+        podium = [d for d in entry.get('podium', []) if d in elo.ratings]
+        if podium:
+            _update_known_pairs(elo, 'race', drivers, podium)
+    return out
+
+
 def backtest_jobs(seasons, seed):
-    """(season, result entry, per-race seed) for every race of the sweep, in calendar order."""
+    """(season, result entry, per-race seed, race fixture) for every race of the sweep, in calendar order."""
     rng = random.Random(seed)
-    return [(season, entry, rng.getrandbits(63)) for season in seasons for entry in load_results(season)]
+    jobs = []
+    for season in seasons:
+        entries = load_results(season)
+        for entry, fx in zip(entries, season_fixtures(season, entries)):
+            jobs.append((season, entry, rng.getrandbits(63), fx))
+    return jobs
 
 
 def shard_jobs(jobs, rank, world):
@@ -95,15 +150,18 @@ def shard_jobs(jobs, rank, world):
 def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, predictor_factory=None):
     """Sweep one prediction per race of each season and score it (reference validation.py:161-209).
 
-    Each race gets its own seed drawn from random.Random(seed) (the reference seeds the global
+    A fresh predictor per race, fed that race's fixture (season_fixtures: Elo evolved over the earlier
+    races).  Each race gets its own seed drawn from random.Random(seed) (the reference seeds the global
     streams once and lets them run on, :172-174; per-race seeds keep races independent so they can
-    shard over GPUs).  Returns the reference's result dict plus per-race rows.
+    shard over GPUs: rank r takes races r, r + world, ...; no collective on the data path, one
+    all_gather_object of the per-race rows at the end).  Returns the reference's result dict plus
+    per-race rows.
     """
     mine = shard_jobs(backtest_jobs(seasons, seed), rank, world)
-    predictor = (predictor_factory or (lambda: F1Predictor(device=device)))()
+    factory = predictor_factory or (lambda: F1Predictor(device=device))
     rows = []
-    for i, (season, entry, race_seed) in mine:
-        res = predictor.predict_weekend(season, entry['race'], synthetic_fixture(), n_simulations=n_simulations,
+    for i, (season, entry, race_seed, fixture) in mine:
+        res = factory().predict_weekend(season, entry['race'], fixture, n_simulations=n_simulations,
                                         seed=race_seed)
         rows.append((i, dict(race=entry['race'], season=season, laps=circuit_info(entry['race'])['laps'],
                              pole=res['pole_probabilities'], win=res['win_probabilities'],
@@ -129,16 +187,26 @@ def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, p
 def cmd_backtest(args) -> int:
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
     device = int(os.environ.get('LOCAL_RANK', str(args.device)))
+    # Rehearsal on a one-GPU box (tests): MCGP_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and gathers over
+    # gloo (RCCL refuses two ranks on one device).  Never set in production launches.
+    share = os.environ.get('MCGP_BENCH_SHARE_GPU') == '1'
+    if share:
+        device = args.device
     if world > 1:
+        from . import _native
+        _native.lib()                     # build / load once before any rank touches the GPU
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(device)
-        dist.init_process_group('nccl')
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(device)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
     t0 = time.perf_counter()
     res = backtest(args.seasons, args.seed, args.simulations, device, rank, world)
     dt = time.perf_counter() - t0
     if rank == 0:
-        print(f"\n{'=' * 60}\nBacktest (offline sweep, synthetic weekend inputs, hand-entered outcomes)\n"
+        print(f"\n{'=' * 60}\nBacktest (offline sweep: synthetic weekends, Elo evolved race by race, hand-entered outcomes)\n"
               f"Seasons: {args.seasons}   simulations per race: {args.simulations}\n{'=' * 60}\n")
         print(f"Races analyzed: {res['n_races']}   ({res['n_races'] * args.simulations / dt:,.0f} simulations/s overall)\n")
         print('BRIER SCORES (lower = better, 0 = perfect)\n' + '-' * 40)

@@ -6,7 +6,7 @@
 // race_kernel.  No CPU compute path exists here: without a HIP device every
 // compute entry point returns MCGP_E_NO_DEVICE.
 #include "../../include/mcgp.h"
-#include "normal_table.h"
+#include "params_build.h"
 #include "race_kernel.hip.h"
 #include "race_kernel_reg.hip.h"
 
@@ -60,11 +60,16 @@ struct DeviceCtx {
         mcgp::KParams *dev = nullptr;
         mcgp::KParams *host = nullptr;        // pinned copy of what `dev` holds
         hipEvent_t done = nullptr;            // recorded after the last launch that reads `dev`
+        hipEvent_t uploaded = nullptr;        // recorded after the upload of `dev`; other streams wait on it
+        hipStream_t upload_stream = nullptr;
         bool used = false;
     } slot[kParamSlots];
     int next_slot = 0;
     unsigned long long *d_hist = nullptr;     // scratch for the host-buffer entry points
     uint8_t *d_grid = nullptr;                // fixed grid for mcgp_simulate_race
+    uint8_t *d_order1 = nullptr;              // one finishing order (mcgp_simulate_race)
+    uint8_t *d_orders = nullptr;              // staging for mcgp_run(orders_out), grown on demand, kept
+    size_t d_orders_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
@@ -81,113 +86,87 @@ int device_count_nothrow()
     return n;
 }
 
-int ensure_ctx(int device, DeviceCtx **out)
+// Validates the device index and returns its context; nothing is initialised yet.
+int find_ctx(int device, DeviceCtx **out)
 {
     const int nd = device_count_nothrow();
     if (nd <= 0) return fail(MCGP_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= nd || device >= kMaxDevices)
         return fail(MCGP_E_NO_DEVICE, "device index out of range");
-    DeviceCtx &c = g_ctx[device];
-    if (!c.ready) {
-        HIP_TRY(hipSetDevice(device));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        c.cu_count = prop.multiProcessorCount;
-        c.lds_per_block = prop.sharedMemPerBlock;       // 160 KiB on gfx950
-        for (auto &sl : c.slot) {
-            HIP_TRY(hipMalloc(&sl.dev, sizeof(mcgp::KParams)));
-            HIP_TRY(hipHostMalloc(&sl.host, sizeof(mcgp::KParams)));
-            HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        }
-        HIP_TRY(hipMalloc(&c.d_hist, sizeof(unsigned long long) * MCGP_MAX_CARS * MCGP_MAX_CARS));
-        HIP_TRY(hipMalloc(&c.d_grid, MCGP_MAX_CARS));
-        HIP_TRY(hipEventCreate(&c.ev_start));
-        HIP_TRY(hipEventCreate(&c.ev_stop));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
-#define X(N_)                                                                                         \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel_reg<N_>),       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
-        MCGP_REG_SIZES(X)
-#undef X
-        c.ready = true;
-    }
-    *out = &c;
+    *out = &g_ctx[device];
     return MCGP_OK;
 }
 
-// u < p for u = w / 2^32  <=>  w < ceil(p * 2^32)   (p * 2^32 is exact in binary64)
-uint64_t threshold(double p)
+void release_ctx(DeviceCtx &c)
 {
-    if (!(p > 0.0)) return 0;                  // also NaN: `u < nan` is false
-    const double x = p * 4294967296.0;
-    if (x >= 4294967296.0) return 4294967296ull;
-    return (uint64_t)std::ceil(x);
+    for (auto &sl : c.slot) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        sl = DeviceCtx::Slot{};
+    }
+    if (c.d_hist) (void)hipFree(c.d_hist);
+    if (c.d_grid) (void)hipFree(c.d_grid);
+    if (c.d_order1) (void)hipFree(c.d_order1);
+    if (c.d_orders) (void)hipFree(c.d_orders);
+    if (c.ev_start) (void)hipEventDestroy(c.ev_start);
+    if (c.ev_stop) (void)hipEventDestroy(c.ev_stop);
+    c.d_hist = nullptr;
+    c.d_grid = c.d_order1 = c.d_orders = nullptr;
+    c.d_orders_bytes = 0;
+    c.ev_start = c.ev_stop = nullptr;
+}
+
+int init_ctx_body(int device, DeviceCtx &c)
+{
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c.cu_count = prop.multiProcessorCount;
+    c.lds_per_block = prop.sharedMemPerBlock;       // 160 KiB on gfx950
+    for (auto &sl : c.slot) {
+        HIP_TRY(hipMalloc(&sl.dev, sizeof(mcgp::KParams)));
+        HIP_TRY(hipHostMalloc(&sl.host, sizeof(mcgp::KParams)));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMalloc(&c.d_hist, sizeof(unsigned long long) * MCGP_MAX_CARS * MCGP_MAX_CARS));
+    HIP_TRY(hipMalloc(&c.d_grid, MCGP_MAX_CARS));
+    HIP_TRY(hipMalloc(&c.d_order1, MCGP_MAX_CARS));
+    HIP_TRY(hipEventCreate(&c.ev_start));
+    HIP_TRY(hipEventCreate(&c.ev_stop));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
+#define X(N_)                                                                                         \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel_reg<N_>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
+    MCGP_REG_SIZES(X)
+#undef X
+    return MCGP_OK;
+}
+
+// First use of a device: the CALLER HOLDS c.mu, so two threads making their first call on one
+// device cannot both initialise it (nor one launch into buffers the other is still creating).
+// A HIP failure part-way releases what was allocated; the next call starts from scratch.
+int ensure_ctx_locked(int device, DeviceCtx &c)
+{
+    if (c.ready) return MCGP_OK;
+    const int rc = init_ctx_body(device, c);
+    if (rc != MCGP_OK) {
+        release_ctx(c);
+        return rc;
+    }
+    c.ready = true;
+    return MCGP_OK;
 }
 
 int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs, uint32_t n,
                  mcgp::KParams *kp)
 {
-    if (!cfg || !drv) return fail(MCGP_E_BAD_ARG, "cfg / drv is NULL");
-    if (n < 1 || n > MCGP_MAX_CARS) return fail(MCGP_E_BAD_ARG, "n must be in [1, 32]");
-    if (cfg->total_laps < 1 || cfg->total_laps > MCGP_MAX_LAPS)
-        return fail(MCGP_E_BAD_ARG, "total_laps must be in [1, 1000]");
-    if (cfg->track_condition < MCGP_DRY || cfg->track_condition > MCGP_WET_TRACK)
-        return fail(MCGP_E_BAD_ARG, "track_condition must be 0 (dry), 1 (damp) or 2 (wet)");
-    if (cfg->pop_soft_hard != MCGP_SOFT && cfg->pop_soft_hard != MCGP_HARD)
-        return fail(MCGP_E_BAD_ARG, "pop_soft_hard must be SOFT or HARD");
-    if (cfg->pop_medium_hard != MCGP_MEDIUM && cfg->pop_medium_hard != MCGP_HARD)
-        return fail(MCGP_E_BAD_ARG, "pop_medium_hard must be MEDIUM or HARD");
-    if (!drv->base_pace || !drv->tire_deg || !drv->tire_deg_pit || !drv->variance || !drv->team_dnf ||
-        !drv->lap_dnf)
-        return fail(MCGP_E_BAD_ARG, "a per-driver array is NULL");
-    std::memset(kp, 0, sizeof(*kp));
-    kp->n = (int32_t)n;
-    kp->total_laps = cfg->total_laps;
-    kp->track = cfg->track_condition;
-    kp->pop_sh = cfg->pop_soft_hard;
-    kp->pop_mh = cfg->pop_medium_hard;
-    kp->pit_loss = cfg->pit_loss;
-    kp->overtake_delta = cfg->overtake_delta;
-    kp->drs_delta = cfg->drs_delta;
-    kp->dirty_thr = cfg->dirty_air_threshold;
-    kp->dirty_pen = cfg->dirty_air_penalty;
-    kp->t_red = threshold(cfg->red_flag_probability);
-    kp->t_sc = threshold(cfg->sc_probability);
-    kp->t_vsc = threshold(cfg->vsc_probability);
-    kp->t_vsc_tire = threshold(0.3);                                   // reference :392
-    for (int c = 0; c < 5; ++c) {
-        kp->comp_deg[c] = cfg->comp_deg_rate[c];
-        kp->comp_delta[c] = cfg->comp_pace_delta[c];
-        if (cfg->comp_optimal_laps[c] < 0 || cfg->comp_optimal_laps[c] > 50000)
-            return fail(MCGP_E_BAD_ARG, "comp_optimal_laps out of range");
-    }
-    for (uint32_t d = 0; d < n; ++d) {
-        const double deg = drv->tire_deg[d];
-        kp->base_pace[d] = drv->base_pace[d];
-        kp->factor[d] = deg > 0 ? deg / 0.05 : 1.0;                    // reference :321
-        kp->tire_deg[d] = deg;
-        kp->variance[d] = drv->variance[d];
-        kp->t_dnf1[d] = threshold(drv->team_dnf[d] * 4.0);             // reference :282,286-287
-        kp->t_dnf[d] = threshold(drv->lap_dnf[d]);
-        const double pit_deg = drv->tire_deg_pit[d];
-        for (int c = 0; c < 5; ++c) {
-            int opt = cfg->comp_optimal_laps[c];                       // reference :455-462
-            if (pit_deg > 0.05) opt = (int)((double)opt * 0.85);
-            else if (pit_deg < 0.02) opt = (int)((double)opt * 1.1);
-            kp->opt_laps[d * mcgp::kCompStride + c] = (uint16_t)opt;
-        }
-    }
-    if (grid_probs)
-        for (uint32_t d = 0; d < n; ++d)
-            for (uint32_t s = 0; s < n; ++s) {
-                const double p = grid_probs[(size_t)d * n + s];
-                if (!(p >= 0.0)) return fail(MCGP_E_BAD_ARG, "grid_probs has a negative or NaN entry");
-                kp->grid_probs[(size_t)d * n + s] = p;
-            }
-    static_assert(sizeof(mcgp_normal_table_bits) == sizeof(kp->normal_bits), "normal table size");
-    std::memcpy(kp->normal_bits, mcgp_normal_table_bits, sizeof(kp->normal_bits));
-    return MCGP_OK;
+    const char *err = "";
+    const int rc = mcgp::build_params(cfg, drv, grid_probs, n, kp, &err);
+    return rc == MCGP_OK ? rc : fail(rc, err);
 }
 
 using KernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, uint32_t, unsigned long long *,
@@ -280,16 +259,26 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kerne
     *lds = (uint32_t)(shared + (size_t)threads * per_thread);
 }
 
+// Most simulations one kernel launch may take.  The per-block LDS histogram counts in uint32 and a cell
+// can receive at most one count per simulation the block runs, so keeping the whole launch below 2^32
+// simulations rules out a silent wrap; longer runs are split into several launches on the same stream
+// (results do not depend on the split: draws are addressed by global simulation id).
+uint64_t max_sims_per_launch()
+{
+    uint64_t cap = 0xFFFFFE00ull;                                       // < 2^32, a multiple of 512
+    if (const char *e = std::getenv("MCGP_MAX_SIMS_PER_LAUNCH")) {      // tests exercise the split with a small cap
+        const unsigned long long v = std::strtoull(e, nullptr, 10);
+        if (v >= 1 && v < cap) cap = v;
+    }
+    return cap;
+}
+
 int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
            hipStream_t stream, unsigned long long *d_hist, uint8_t *d_orders, const uint8_t *d_fixed_grid)
 {
     if (n_sims == 0) return MCGP_OK;
-    uint32_t grid, block, lds;
     bool is_reg = false;
     const KernelFn kernel = select_kernel((uint32_t)kp.n, &is_reg);
-    launch_geometry(c, (uint32_t)kp.n, is_reg, kernel, n_sims, &grid, &block, &lds);
-    const uint64_t n_batches = (n_sims + block - 1) / block;
-    if (n_batches > 0xffffffffull) return fail(MCGP_E_BAD_ARG, "n_sims too large for one launch");
     DeviceCtx::Slot *sl = nullptr;
     for (auto &cand : c.slot)
         if (cand.used && std::memcmp(cand.host, &kp, sizeof(kp)) == 0) { sl = &cand; break; }
@@ -300,12 +289,25 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         std::memcpy(sl->host, &kp, sizeof(kp));
         sl->used = true;
         HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, sizeof(kp), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(sl->uploaded, stream));
+        sl->upload_stream = stream;
+    } else if (sl->upload_stream != stream) {
+        // cached block uploaded on another stream: order this stream behind that upload
+        HIP_TRY(hipStreamWaitEvent(stream, sl->uploaded, 0));
     }
     HIP_TRY(hipEventRecord(c.ev_start, stream));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, n_sims,
-                       sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32), d_hist, d_orders, d_fixed_grid,
-                       (uint32_t)n_batches);
-    HIP_TRY(hipGetLastError());
+    const uint64_t cap = max_sims_per_launch();
+    uint32_t grid = 0, block = 0, lds = 0;
+    for (uint64_t done = 0; done < n_sims; done += cap) {
+        const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
+        launch_geometry(c, (uint32_t)kp.n, is_reg, kernel, m, &grid, &block, &lds);
+        const uint64_t n_batches = (m + block - 1) / block;             // < 2^32 because m < 2^32
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
+                           d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
+                           (uint32_t)n_batches);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(c.ev_stop, stream));
     HIP_TRY(hipEventRecord(sl->done, stream));
     c.timed = true;
@@ -336,13 +338,16 @@ int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const d
     if (!kp) return fail(MCGP_E_NOMEM, "host allocation failed");
     int rc = build_params(cfg, drv, grid_probs, n, kp);
     DeviceCtx *c = nullptr;
-    if (rc == MCGP_OK) rc = ensure_ctx(device, &c);
+    if (rc == MCGP_OK) rc = find_ctx(device, &c);
     if (rc == MCGP_OK) {
         std::lock_guard<std::mutex> lock(c->mu);
-        hipError_t e = hipSetDevice(device);
-        if (e != hipSuccess) rc = fail(MCGP_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-        else rc = launch(*c, *kp, n_sims, sim_offset, seed, (hipStream_t)stream,
-                         reinterpret_cast<unsigned long long *>(d_hist), d_orders, nullptr);
+        rc = ensure_ctx_locked(device, *c);
+        if (rc == MCGP_OK) {
+            hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) rc = fail(MCGP_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+            else rc = launch(*c, *kp, n_sims, sim_offset, seed, (hipStream_t)stream,
+                             reinterpret_cast<unsigned long long *>(d_hist), d_orders, nullptr);
+        }
     }
     delete kp;
     return rc;
@@ -357,18 +362,29 @@ int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
     if (!kp) return fail(MCGP_E_NOMEM, "host allocation failed");
     int rc = build_params(cfg, drv, grid_probs, n, kp);
     DeviceCtx *c = nullptr;
-    if (rc == MCGP_OK) rc = ensure_ctx(device, &c);
+    if (rc == MCGP_OK) rc = find_ctx(device, &c);
     if (rc != MCGP_OK) { delete kp; return rc; }
     std::lock_guard<std::mutex> lock(c->mu);
     auto body = [&]() -> int {
+        int r = ensure_ctx_locked(device, *c);
+        if (r != MCGP_OK) return r;
         HIP_TRY(hipSetDevice(device));
         const size_t hist_bytes = sizeof(unsigned long long) * n * n;
         HIP_TRY(hipMemsetAsync(c->d_hist, 0, hist_bytes, nullptr));
-        // per-simulation orders are staged in chunks so the device buffer stays bounded
+        // per-simulation orders are staged in chunks so the device buffer stays bounded; the staging
+        // buffer is kept in the context (grown on demand), not allocated per call
         const uint64_t chunk = orders_out ? (uint64_t)(1u << 22) : n_sims;
-        uint8_t *d_orders = nullptr;
-        if (orders_out && n_sims) HIP_TRY(hipMalloc(&d_orders, (size_t)(chunk < n_sims ? chunk : n_sims) * n));
-        int r = MCGP_OK;
+        if (orders_out && n_sims) {
+            const size_t want = (size_t)(chunk < n_sims ? chunk : n_sims) * n;
+            if (want > c->d_orders_bytes) {
+                if (c->d_orders) (void)hipFree(c->d_orders);
+                c->d_orders = nullptr;
+                c->d_orders_bytes = 0;
+                HIP_TRY(hipMalloc(&c->d_orders, want));
+                c->d_orders_bytes = want;
+            }
+        }
+        uint8_t *d_orders = orders_out ? c->d_orders : nullptr;
         for (uint64_t done = 0; done < n_sims && r == MCGP_OK; done += chunk) {
             const uint64_t m = (n_sims - done) < chunk ? (n_sims - done) : chunk;
             r = launch(*c, *kp, m, sim_offset + done, seed, nullptr, c->d_hist, d_orders, nullptr);
@@ -377,7 +393,6 @@ int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
                 if (e != hipSuccess) r = fail(MCGP_E_HIP, std::string("hipMemcpy(orders): ") + hipGetErrorString(e));
             }
         }
-        if (d_orders) (void)hipFree(d_orders);
         if (r != MCGP_OK) return r;
         unsigned long long h[MCGP_MAX_CARS * MCGP_MAX_CARS];
         HIP_TRY(hipMemcpy(h, c->d_hist, hist_bytes, hipMemcpyDeviceToHost));
@@ -404,21 +419,20 @@ int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, cons
     if (!kp) return fail(MCGP_E_NOMEM, "host allocation failed");
     int rc = build_params(cfg, drv, nullptr, n, kp);
     DeviceCtx *c = nullptr;
-    if (rc == MCGP_OK) rc = ensure_ctx(device, &c);
+    if (rc == MCGP_OK) rc = find_ctx(device, &c);
     if (rc != MCGP_OK) { delete kp; return rc; }
     std::lock_guard<std::mutex> lock(c->mu);
     auto body = [&]() -> int {
+        int r = ensure_ctx_locked(device, *c);
+        if (r != MCGP_OK) return r;
         HIP_TRY(hipSetDevice(device));
-        uint8_t *d_order = nullptr;
-        HIP_TRY(hipMalloc(&d_order, MCGP_MAX_CARS));
         HIP_TRY(hipMemcpy(c->d_grid, grid, n, hipMemcpyHostToDevice));
         HIP_TRY(hipMemsetAsync(c->d_hist, 0, sizeof(unsigned long long) * n * n, nullptr));
-        int r = launch(*c, *kp, 1, sim_id, seed, nullptr, c->d_hist, d_order, c->d_grid);
+        r = launch(*c, *kp, 1, sim_id, seed, nullptr, c->d_hist, c->d_order1, c->d_grid);
         if (r == MCGP_OK) {
-            hipError_t e = hipMemcpy(order_out, d_order, n, hipMemcpyDeviceToHost);
+            hipError_t e = hipMemcpy(order_out, c->d_order1, n, hipMemcpyDeviceToHost);
             if (e != hipSuccess) r = fail(MCGP_E_HIP, std::string("hipMemcpy(order): ") + hipGetErrorString(e));
         }
-        (void)hipFree(d_order);
         return r;
     };
     rc = body();
@@ -429,10 +443,10 @@ int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, cons
 int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out)
 {
     if (!ms_out) return fail(MCGP_E_BAD_ARG, "ms_out is NULL");
-    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready || !g_ctx[device].timed)
-        return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
+    if (device < 0 || device >= kMaxDevices) return fail(MCGP_E_BAD_ARG, "device index out of range");
     DeviceCtx &c = g_ctx[device];
     std::lock_guard<std::mutex> lock(c.mu);
+    if (!c.ready || !c.timed) return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipEventSynchronize(c.ev_stop));
     HIP_TRY(hipEventElapsedTime(ms_out, c.ev_start, c.ev_stop));

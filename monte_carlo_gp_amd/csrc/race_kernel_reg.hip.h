@@ -25,6 +25,7 @@
 // cost is N/2 + 1 Philox calls plus one per four overtake attempts.
 #pragma once
 #include "race_common.hip.h"
+#include "race_isa.hip.h"
 
 // Diagnostic builds only (tools/ablate.sh): bit k set = run section k twice (each section is
 // idempotent, results unchanged) so its cost shows up as a time difference.  0 in the product build.
@@ -83,16 +84,6 @@ struct MergeExchange {
         }
     }
 };
-
-// v_min_f64 / v_max_f64 issued directly: through fmin()/fmax() hipcc adds a canonicalising
-// v_max_f64 x, x, x per operand (IEEE mode quiets signalling NaNs), tripling the cost.  Times are
-// finite and non-negative here, for which the bare instructions are exact.  Plain VALU, interlocked
-// by hardware: no wait states needed inside the statement.
-__device__ __forceinline__ void minmax_f64(double a, double b, double &lo, double &hi)
-{
-    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
-    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-}
 
 // compare-exchange on (cum, pk): after it, slot A sorts before slot B.
 __device__ __forceinline__ bool cmpx(double &ca, uint32_t &pa, double &cb, uint32_t &pb)

@@ -14,6 +14,12 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """Multi-process GPU tests first: their children must be started while this process has not yet
+    initialised the GPU (a GPU-initialised parent must not fork+exec on the GPU pool)."""
+    items.sort(key=lambda it: 0 if 'test_gpu_multiproc' in it.nodeid else 1)      # stable
+
+
 @pytest.fixture(scope='session')
 def require_gpu():
     """GPU tests must fail loudly (not skip) when the HIP path cannot run."""

@@ -1,0 +1,56 @@
+"""Host DEBUGGING build of the kernel sources (tools/emu): compile, load, run.  Test infrastructure only --
+the product (monte_carlo_gp_amd/) never imports this and has no CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU_DIR = os.path.join(ROOT, 'tools', 'emu')
+LIB = os.path.join(EMU_DIR, 'libmcgp_emu.so')
+CSRC = os.path.join(ROOT, 'monte_carlo_gp_amd', 'csrc')
+
+_lib = None
+
+
+def build():
+    srcs = [os.path.join(EMU_DIR, f) for f in ('emu_kernel.cpp', 'race_isa_host.h', 'hip/hip_runtime.h')]
+    srcs += [os.path.join(CSRC, f) for f in ('race_kernel_reg.hip.h', 'race_common.hip.h', 'params_build.h', 'normal_table.h')]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared',
+                               '-I' + EMU_DIR, '-o', LIB, os.path.join(EMU_DIR, 'emu_kernel.cpp')])
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.emu_run.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def run(case, n_sims, seed, sim_offset=0, set_pop=None, fixed_grid=None):
+    """(hist, orders) of the kernel source executed on the host for a golden-case dict."""
+    from monte_carlo_gp_amd import RaceConfig
+    from monte_carlo_gp_amd.simulation import RaceSimulator, _Problem, _dptr
+    import oracle_py as O
+    drivers = list(case['grid_probs'])
+    p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
+                 case['driver_dnf_rates'], case['track_condition'], set_pop or O.load_cases()['set_pop'])
+    g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+    n = p.n
+    hist = np.zeros((n, n), np.uint64)
+    orders = np.zeros((n_sims, n), np.uint8)
+    err = C.c_char_p()
+    fg = None
+    if fixed_grid is not None:
+        fg = np.ascontiguousarray(fixed_grid, np.uint8).ctypes.data_as(C.c_void_p)
+    rc = lib().emu_run(C.byref(p.cfg), C.byref(p.drv), _dptr(g), C.c_uint32(n), C.c_uint64(n_sims),
+                       C.c_uint64(sim_offset), C.c_uint64(seed), hist.ctypes.data_as(C.c_void_p),
+                       orders.ctypes.data_as(C.c_void_p), fg, C.byref(err))
+    assert rc == 0, err.value
+    return hist.astype(np.int64), orders

@@ -40,11 +40,37 @@ def test_backtest_sweep_scoring_and_sharding():
     assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
 
 
+def test_per_race_fixtures_follow_the_elo_trajectory():
+    """f2: every race of the sweep gets its own fixture -- the Elo the earlier races produced
+    (reference src/validation.py:179-205), so races differ by more than circuit constants."""
+    from monte_carlo_gp_amd.predictor import F1Predictor
+    entries = cli.load_results(2024)
+    fx = cli.season_fixtures(2024, entries)
+    assert len(fx) == 24 and fx == cli.season_fixtures(2024, entries)          # deterministic
+    base = cli.synthetic_fixture()
+    assert fx[0]['quali_ratings'] == base['quali_ratings']                     # nothing has happened before race 1
+    assert len({tuple(f['quali_ratings'].values()) for f in fx}) == 24         # a distinct rating vector per race
+    # VER took the first seven poles: his quali rating climbs over them; NOR's rises with his late-season poles
+    ver = [f['quali_ratings']['VER'] for f in fx]
+    assert all(b > a for a, b in zip(ver[:7], ver[1:8]))
+    assert fx[23]['quali_ratings']['NOR'] > fx[0]['quali_ratings']['NOR'] > fx[9]['quali_ratings']['NOR']
+    # rating mass is conserved by the pairwise update (zero-sum), as in the reference's Elo
+    assert sum(fx[23]['quali_ratings'].values()) == pytest.approx(sum(base['quali_ratings'].values()), abs=1e-6)
+    # and the grid matrix the simulator receives moves with it
+    g0 = F1Predictor(device=0).simulator_inputs(fx[0], 'Bahrain')['grid_probs']
+    g23 = F1Predictor(device=0).simulator_inputs(fx[23], 'Abu Dhabi')['grid_probs']
+    assert g0['NOR'][0] < g23['NOR'][0] and g0['VER'] != g23['VER']
+    # the jobs of the sweep carry these fixtures
+    jobs = cli.backtest_jobs([2024], 42)
+    assert [j[3]['race_index'] for j in jobs] == list(range(24))
+
+
 def test_results_fixture_is_flagged_and_consistent():
     races = cli.load_results(2024)
     assert len(races) == 24
     for r in races:
         assert r['winner'] == r['podium'][0] and len(r['podium']) == 3
+    assert {r['race']: r['pole'] for r in races}['Qatar'] == 'RUS'             # pole STARTER convention (ADVICE r1)
     with open(cli.__file__.replace('cli.py', 'data/results_2024.json')) as f:
         assert 'HAND-ENTERED' in json.load(f)['_note']
 
@@ -83,3 +109,24 @@ def test_backtest_sweep_on_gpu(require_gpu):
     assert 0.0 < res['win_brier'] < 0.2 and 0.0 <= res['podium_accuracy'] <= 1.0
     again = cli.backtest([2024], seed=42, n_simulations=200000)
     assert again['win_brier'] == res['win_brier'] and again['pole_brier'] == res['pole_brier']
+
+
+@pytest.mark.gpu
+def test_backtest_sweep_full_size(require_gpu):
+    """BASELINE configs[4] on one GPU: the 2024 calendar x 10^7 simulations per race (reference
+    src/validation.py:161-209), each race on its own fixture.  Scores are compared with the 2x10^5-simulation
+    sweep: same races, same fixtures, different seeds/sizes -> win probabilities agree to Monte Carlo error."""
+    import time
+    t0 = time.perf_counter()
+    big = cli.backtest([2024], seed=7, n_simulations=10_000_000)
+    dt = time.perf_counter() - t0
+    small = cli.backtest([2024], seed=42, n_simulations=200_000)
+    assert big['n_races'] == 24 and dt < 120
+    for a, b in zip(big['races'], small['races']):
+        assert a['race'] == b['race'] and a['pole'] == b['pole']                # pole model has no Monte Carlo in it
+        assert abs(sum(a['win'].values()) - 1.0) < 1e-9
+        for d in a['win']:
+            p = a['win'][d]
+            assert abs(p - b['win'][d]) < 5.0 * (p * (1 - p) / 200_000) ** 0.5 + 1e-4, (a['race'], d)
+    assert abs(big['win_brier'] - small['win_brier']) < 2e-4
+    assert big['pole_brier'] == small['pole_brier']

@@ -149,3 +149,81 @@ def test_concurrent_calls_from_two_threads(require_gpu):
         got = list(ex.map(work, range(8)))
     for i, h in enumerate(got):
         assert np.array_equal(h, O.Problem(cases[i % 2]).run(20000, rng=O.RNG_PHILOX, seed=100 + i)['hist']), i
+
+
+def test_run_simulations_alias(require_gpu):
+    """North-star call surface run_simulations(grid, n_sims, seed): a thin wrapper over run_monte_carlo with the
+    per-race inputs given to set_race_inputs(); without them the reference's .get() defaults apply
+    (base pace 90.0, degradation 0.05, variance 0.15, team DNF rates; reference src/simulation.py:190-204)."""
+    case = O.load_case('S60')
+    sim = product_sim(case)
+    sim.set_race_inputs(case['base_pace'], case['tire_deg'], case['driver_variance'], case['driver_dnf_rates'],
+                        case['track_condition'])
+    got = sim.run_simulations(case['grid_probs'], 4000, 42)
+    ref = O.Problem(case).run(4000, rng=O.RNG_PHILOX, seed=42)['hist']
+    assert np.array_equal(sim.last_histogram, ref)
+    direct = product_sim(case).run_monte_carlo(4000, case['grid_probs'], case['base_pace'], case['tire_deg'],
+                                               case['driver_variance'], case['driver_dnf_rates'], seed=42,
+                                               track_condition=case['track_condition'])
+    assert got == direct
+    # no inputs set: every dict falls back to the reference defaults, which is the oracle on empty dicts
+    bare = product_sim(case)
+    bare.run_simulations(case['grid_probs'], 3000, 7)
+    dflt = dict(case, base_pace={}, tire_deg={}, driver_variance={}, driver_dnf_rates=None)
+    assert np.array_equal(bare.last_histogram, O.Problem(dflt).run(3000, rng=O.RNG_PHILOX, seed=7)['hist'])
+
+
+def test_long_runs_split_into_launches(require_gpu, monkeypatch):
+    """A run longer than the per-launch cap (2^32 - 512 simulations; the block histogram counts in uint32) is
+    split into several launches; with the cap lowered to 1000 the seams are exercised: same orders, same histogram."""
+    case = O.load_case('N10')
+    ref = O.Problem(case).run(3500, rng=O.RNG_PHILOX, seed=11, sim_offset=77, want_orders=True)
+    monkeypatch.setenv('MCGP_MAX_SIMS_PER_LAUNCH', '1000')
+    hist, _, orders = product_run(case, 3500, 11, sim_offset=77, orders=True)
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+
+
+def test_cached_parameter_block_across_streams(require_gpu):
+    """mcgp_run_device on stream A, then the same problem on stream B and on the NULL stream: the cached
+    parameter block is re-used behind an event wait on its upload.  Streams and buffers come
+    straight from the HIP runtime the library itself is linked against (no second runtime in the process)."""
+    import ctypes as C
+    from monte_carlo_gp_amd import _native as N
+    from monte_carlo_gp_amd.simulation import _Problem, _dptr, RaceSimulator
+    from monte_carlo_gp_amd import RaceConfig
+    hip = C.CDLL('/opt/rocm/lib/libamdhip64.so')
+
+    def ok(rc):
+        assert rc == 0, f'HIP error {rc}'
+    ok(hip.hipSetDevice(0))
+    streams = []
+    for _ in range(2):
+        st = C.c_void_p()
+        ok(hip.hipStreamCreateWithFlags(C.byref(st), 1))          # hipStreamNonBlocking
+        streams.append(st)
+    streams.append(C.c_void_p(0))                                 # the NULL stream
+    for name, seed in (('EVT', 5), ('DMP', 6), ('HET', 7), ('S50', 8), ('N10', 9)):       # more problems than cache slots
+        case = O.load_case(name)
+        drivers = list(case['grid_probs'])
+        p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'],
+                     case['driver_variance'], case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
+        g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+        nbytes = p.n * p.n * 8
+        bufs = []
+        for _ in streams:
+            d = C.c_void_p()
+            ok(hip.hipMalloc(C.byref(d), C.c_size_t(nbytes)))
+            ok(hip.hipMemset(d, 0, C.c_size_t(nbytes)))
+            bufs.append(d)
+        ok(hip.hipDeviceSynchronize())
+        for st, d in zip(streams, bufs):
+            N.check(N.lib().mcgp_run_device(C.byref(p.cfg), C.byref(p.drv), _dptr(g), p.n, 5000, 0, seed, 0, st, d, None))
+        ok(hip.hipDeviceSynchronize())
+        ref = O.Problem(case).run(5000, rng=O.RNG_PHILOX, seed=seed)['hist']
+        for d in bufs:
+            h = np.zeros((p.n, p.n), np.uint64)
+            ok(hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), d, C.c_size_t(nbytes), 2))      # device -> host
+            ok(hip.hipFree(d))
+            assert np.array_equal(h.astype(np.int64), ref), name
+    for st in streams[:2]:
+        ok(hip.hipStreamDestroy(st))

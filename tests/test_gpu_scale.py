@@ -14,7 +14,7 @@ def _check_latin(hist, n_sims):
     assert (hist.sum(axis=0) == n_sims).all() and (hist.sum(axis=1) == n_sims).all()
 
 
-@pytest.mark.parametrize('name,n_sims', [('S60', 10_000_000), ('S78', 4_000_000)])
+@pytest.mark.parametrize('name,n_sims', [('S60', 10_000_000), ('S78', 10_000_000)])
 def test_full_size_run_properties(require_gpu, name, n_sims):
     case = O.load_case(name)
     hist, probs, _ = product_run(case, n_sims, 42)

@@ -1,0 +1,45 @@
+"""The register kernel's SOURCE (csrc/race_kernel_reg.hip.h), compiled for the host by tools/emu and run one
+thread at a time, against the CPU oracle's Philox back-end: bit-exact finishing orders and histograms.
+
+This is a CPU-side regression net for the kernel's race logic (it runs without a GPU, in seconds); the parity
+tests proper are the -m gpu tests, which run the gfx950 build through the C ABI.  The host build is test
+infrastructure: nothing under monte_carlo_gp_amd/ can reach it and the product has no CPU path."""
+import json
+
+import numpy as np
+import pytest
+
+import kernel_host_build as K
+import oracle_py as O
+
+
+@pytest.mark.parametrize('name', ['S60', 'S78', 'S50', 'EVT', 'HET', 'DMP', 'WET', 'N10'])
+def test_golden_cases(name):
+    case = O.load_case(name)
+    n_sims = 600
+    ref = O.Problem(case).run(n_sims, rng=O.RNG_PHILOX, seed=42, want_orders=True)
+    hist, orders = K.run(case, n_sims, 42)
+    bad = np.nonzero((orders != ref['orders']).any(axis=1))[0]
+    assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
+    assert np.array_equal(hist, ref['hist'])
+
+
+def test_fuzzed_configurations():
+    with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
+        cases = json.load(f)
+    for name, c in cases.items():
+        if not (2 <= len(c['grid_probs']) <= 24):
+            continue                                   # field sizes served by the generic LDS kernel
+        ref = O.Problem(c).run(300, rng=O.RNG_PHILOX, seed=c['seed'], want_orders=True)
+        hist, orders = K.run(c, 300, c['seed'])
+        bad = np.nonzero((orders != ref['orders']).any(axis=1))[0]
+        assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
+        assert np.array_equal(hist, ref['hist']), name
+
+
+def test_offsets_and_64bit_seeds():
+    case = O.load_case('S50')
+    seed, base = 0xDEADBEEFCAFEF00D, (1 << 40) + 12345
+    ref = O.Problem(case).run(400, rng=O.RNG_PHILOX, seed=seed, sim_offset=base, want_orders=True)
+    hist, orders = K.run(case, 400, seed, sim_offset=base)
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])

@@ -1,0 +1,46 @@
+// emu_kernel.cpp -- DEBUGGING build of the register kernel's source for the host (not product code, not a
+// fallback: nothing in monte_carlo_gp_amd/ can reach it).  Compiles csrc/race_kernel_reg.hip.h with g++ through
+// the stand-in <hip/hip_runtime.h> of this directory and runs it one "thread" at a time (blockDim.x == 1), so a
+// kernel edit can be compared with the oracle on the CPU before a GPU run.  tests/test_kernel_host_build.py.
+//   g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Itools/emu -o tools/emu/libmcgp_emu.so tools/emu/emu_kernel.cpp
+#include "race_isa_host.h"
+
+#include "../../monte_carlo_gp_amd/csrc/params_build.h"
+#include "../../monte_carlo_gp_amd/csrc/race_kernel_reg.hip.h"
+
+#include <vector>
+
+emu_dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+namespace mcgp {
+alignas(16) unsigned char smem[1 << 20];
+}
+
+#define EMU_SIZES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) \
+    X(19) X(20) X(21) X(22) X(23) X(24)
+
+extern "C" int emu_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs, uint32_t n,
+                       uint64_t n_sims, uint64_t sim_offset, uint64_t seed, unsigned long long *hist,
+                       uint8_t *orders, const uint8_t *fixed_grid, const char **err)
+{
+    static mcgp::KParams kp;
+    static const char *none = "";
+    *err = none;
+    const int rc = mcgp::build_params(cfg, drv, grid_probs, n, &kp, err);
+    if (rc != MCGP_OK) return rc;
+    threadIdx = {0, 0, 0};
+    blockIdx = {0, 0, 0};
+    blockDim = {1, 1, 1};
+    gridDim = {1, 1, 1};
+    switch (n) {
+#define X(N_)                                                                                                   \
+    case N_:                                                                                                    \
+        mcgp::race_kernel_reg<N_>(&kp, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32), hist, orders, \
+                                  fixed_grid, (uint32_t)n_sims);                                                \
+        return 0;
+        EMU_SIZES(X)
+#undef X
+        default:
+            *err = "no register instantiation for this field size";
+            return -1;
+    }
+}

@@ -1,0 +1,47 @@
+// hip/hip_runtime.h -- HOST stand-in used ONLY by tools/emu (a debugging build of the kernel sources for the CPU).
+// It lets csrc/race_kernel_reg.hip.h compile with g++ so that a kernel edit can be checked against the oracle in
+// seconds before it is sent to a GPU.  Execution model: ONE thread per "block" (blockDim.x == 1), blocks run one
+// after another; __syncthreads() is then a no-op and LDS is a plain array.  Nothing under monte_carlo_gp_amd/
+// includes or links this: the product has no CPU path.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__
+#define __align__(x)
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct emu_dim3 {
+    unsigned x, y, z;
+};
+extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+struct float4 {
+    float x, y, z, w;
+};
+
+inline void __syncthreads() {}
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+inline float __uint_as_float(uint32_t u)
+{
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+template <typename T>
+inline T atomicAdd(T *p, T v)
+{
+    const T old = *p;
+    *p = old + v;
+    return old;
+}
