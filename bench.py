@@ -43,6 +43,23 @@ VALU_PEAK_TINST = 1024 * 2.4e9 / 2 / 1e12   # 256 CUs x 4 SIMD-32, one wave64 VA
 def load_workload(name):
     with open(os.path.join(ROOT, 'tests', 'golden', 'cases.json')) as f:
         meta = json.load(f)
+    if name == 'N25':
+        # 25-car field (no register instantiation: served by the generic LDS kernel), S60 parameters
+        base = meta['cases']['S60']
+        drivers = [f'D{i:02d}' for i in range(25)]
+        teams = list(base['config']['dnf_rates'])
+        n = len(drivers)
+        sigma = n / 4
+        grid = {}
+        for i, d in enumerate(drivers):
+            w = [np.exp(-((j - i) ** 2) / (2 * sigma ** 2)) for j in range(n)]
+            grid[d] = [float(x / sum(w)) for x in w]
+        case = dict(base, grid_probs=grid,
+                    config=dict(base['config'], driver_teams={d: teams[i % len(teams)] for i, d in enumerate(drivers)}),
+                    base_pace={d: 90.0 + 0.1 * i for i, d in enumerate(drivers)}, tire_deg={d: 0.05 for d in drivers},
+                    driver_variance={d: 0.18 for d in drivers},
+                    driver_dnf_rates={d: 0.05 / base['config']['total_laps'] for d in drivers})
+        return case, meta['set_pop']
     return meta['cases'][name], meta['set_pop']
 
 
@@ -60,7 +77,23 @@ def host_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return dict(cpu_model=model, nproc=os.cpu_count() or 1, usable_cores=usable)
+    # CPU share of this job: cgroup v2 quota if one is set, else the affinity mask; a one-GPU box of the pool
+    # gives 16 cores to a job whatever nproc says, so the thread count is capped there unless overridden
+    threads, source = usable, 'affinity mask'
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            threads, source = max(1, int(int(quota) / int(period))), 'cgroup cpu.max'
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get('MCGP_BENCH_CPU_THREADS')
+    if env:
+        threads, source = max(1, int(env)), 'MCGP_BENCH_CPU_THREADS'
+    elif threads > 16:
+        threads, source = 16, f'capped at the 16-core share of a one-GPU job ({source} says {threads})'
+    return dict(cpu_model=model, nproc=os.cpu_count() or 1, usable_cores=usable, bench_threads=threads,
+                bench_threads_source=source)
 
 
 def cpu_baseline(case_name, seconds=12.0, all_core_seconds=8.0):
@@ -88,27 +121,30 @@ def cpu_baseline(case_name, seconds=12.0, all_core_seconds=8.0):
                reference_python_sims_per_s={'S60': 180, 'S78': 139,
                                             'note': 'the pure-Python reference itself, 1 core of the build container '
                                                     '(SURVEY.md section 6 probe); it cannot travel to the GPU box'})
-    # all-core leg: calibrate one thread for ~1 s, then size the sample for all_core_seconds on every core
-    t0 = time.perf_counter()
-    P.run(chunk, rng=O.RNG_PHILOX, seed=42)
-    one = chunk / (time.perf_counter() - t0)
-    cores = info['usable_cores']
-    per_thread = max(chunk, int(one * all_core_seconds / chunk) * chunk)
+    # all-core leg: one thread per core of this job's CPU share, each running chunks until a common deadline
+    # (bounded wall time whatever the share turns out to be)
+    cores = info['bench_threads']
     problems = [O.Problem(O.load_case(case_name)) for _ in range(cores)]
+    t0 = time.perf_counter()
+    problems[0].run(chunk, rng=O.RNG_PHILOX, seed=42)
+    one = chunk / (time.perf_counter() - t0)
+    stride = 1 << 32                                   # disjoint simulation-id ranges per thread
+    deadline = time.perf_counter() + all_core_seconds
 
     def work(i):
-        left, off = per_thread, i * per_thread
-        while left > 0:
+        n, off = 0, i * stride
+        while time.perf_counter() < deadline:
             problems[i].run(chunk, rng=O.RNG_PHILOX, seed=42, sim_offset=off)
-            left -= chunk
+            n += chunk
             off += chunk
-        return per_thread
+        return n
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     out['all_cores'] = dict(value=total / dt, unit='race-simulations/s', cores=cores, kind='port',
-                            sample=f'{total} simulations of {case_name} (Philox back-end), {dt:.1f} s, {cores} threads',
+                            sample=f'{total} simulations of {case_name} (Philox back-end), {dt:.1f} s, {cores} threads '
+                                   f"({info['bench_threads_source']})",
                             one_thread_philox=one)
     return out
 
@@ -143,6 +179,7 @@ def main():
     ap.add_argument('--sims-per-step', type=int, default=SIMS_PER_STEP)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the S78 and orders-mode side measurements')
+    ap.add_argument('--orders', action='store_true', help='the timed steps also write the per-simulation finishing orders')
     args = ap.parse_args()
 
     import torch
@@ -244,7 +281,7 @@ def main():
                     kernel_ms=float(np.mean(kernel_ms)), kernel=lib.mcgp_last_kernel_name(local_rank).decode(),
                     launch={'grid': g.value, 'block': b.value, 'lds_bytes': lds.value})
 
-    r = run_workload(args.workload, args.steps, args.warmup)
+    r = run_workload(args.workload, args.steps, args.warmup, with_orders=args.orders)
     if rank == 0:
         n, L, kavg_ms, hist = r['n'], r['L'], r['kernel_ms'], r['hist']
         achieved = per_gpu * ALGORITHMIC_BYTES_PER_SIM / (kavg_ms * 1e-3) / 1e9

@@ -198,8 +198,9 @@ KernelFn select_kernel(uint32_t n, bool *is_reg)
     }
 }
 
-// Launch geometry: persistent blocks striding over batches of blockDim.x simulations; as many
-// waves per CU as LDS allows.
+// Launch geometry: persistent blocks striding over batches of `block` simulations.  The register kernel's
+// block size and LDS footprint are compile-time functions of the field size (RegGeo<N>, shared with the
+// kernel); the number of blocks per CU follows from LDS and the kernel's register allocation.
 void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kernel, uint64_t n_sims, uint32_t *grid,
                      uint32_t *block, uint32_t *lds)
 {
@@ -215,48 +216,41 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kerne
             reg_cap = 4 * per_simd;
         }
     }
-    const size_t per_thread = is_reg ? mcgp::per_thread_lds_bytes_reg((int)n) : mcgp::per_thread_lds_bytes((int)n);
-    const size_t shared = is_reg ? mcgp::shared_lds_bytes_reg((int)n) : mcgp::kSharedTableBytes;
-    const size_t per_wave = 64 * per_thread;
     int waves = 1, blocks_per_cu = 1;
+    size_t bytes = 0;
     if (is_reg) {
-        // blocks of <= 8 waves (__launch_bounds__(512, ..)); take the (waves per block, blocks per CU)
-        // pair that keeps most waves resident within the LDS budget and the register cap; among equals
-        // prefer at least 4 waves per block (fewer copies of the shared tables), then the smaller block
-        int best = 0;
-        for (int w = 1; w <= 8; ++w) {
-            int b = (int)(c.lds_per_block / (shared + (size_t)w * per_wave));
-            if (b * w > reg_cap) b = reg_cap / w;
-            if (b >= 1 && (b * w > best || (b * w == best && waves < 4))) { best = b * w; waves = w; blocks_per_cu = b; }
-        }
+        waves = mcgp::reg_block_waves((int)n);
+        bytes = mcgp::shared_lds_bytes_reg((int)n) + (size_t)waves * 64 * mcgp::per_thread_lds_bytes_reg((int)n);
     } else {
-        waves = (int)((c.lds_per_block - shared) / per_wave);
+        const size_t per_wave = 64 * mcgp::per_thread_lds_bytes((int)n);
+        waves = (int)((c.lds_per_block - mcgp::kSharedTableBytes) / per_wave);
         if (waves > 8) waves = 8;
         if (waves < 1) waves = 1;
-    }
-    if (const char *e = std::getenv("MCGP_WAVES_PER_BLOCK")) {          // tuning / diagnostics
-        const int w = std::atoi(e);
-        if (w >= 1 && w <= waves) {
-            waves = w;
-            blocks_per_cu = (int)(c.lds_per_block / (shared + (size_t)waves * per_wave));
-            if (blocks_per_cu < 1) blocks_per_cu = 1;
-            if (blocks_per_cu * waves > reg_cap) blocks_per_cu = reg_cap / waves;
+        if (const char *e = std::getenv("MCGP_WAVES_PER_BLOCK")) {          // tuning / diagnostics (generic kernel only)
+            const int w = std::atoi(e);
+            if (w >= 1 && w <= waves) waves = w;
         }
+        uint32_t threads = (uint32_t)waves * 64u;
+        if (n_sims < threads) threads = (uint32_t)(((n_sims + 63) / 64) * 64);
+        if (threads == 0) threads = 64;
+        waves = (int)(threads / 64);
+        bytes = mcgp::kSharedTableBytes + (size_t)threads * mcgp::per_thread_lds_bytes((int)n);
     }
+    blocks_per_cu = (int)(c.lds_per_block / bytes);
+    if (blocks_per_cu * waves > reg_cap) blocks_per_cu = reg_cap / waves;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
     if (const char *e = std::getenv("MCGP_MAX_BLOCKS_PER_CU")) {
         const int m = std::atoi(e);
         if (m >= 1 && m < blocks_per_cu) blocks_per_cu = m;
     }
-    uint32_t threads = (uint32_t)waves * 64u;
-    if (n_sims < threads) threads = (uint32_t)(((n_sims + 63) / 64) * 64);
-    if (threads == 0) threads = 64;
+    const uint32_t threads = (uint32_t)waves * 64u;
     const uint64_t n_batches = (n_sims + threads - 1) / threads;
     uint64_t g = (uint64_t)c.cu_count * (uint64_t)blocks_per_cu;
     if (g > n_batches) g = n_batches;
     if (g < 1) g = 1;
     *grid = (uint32_t)g;
     *block = threads;
-    *lds = (uint32_t)(shared + (size_t)threads * per_thread);
+    *lds = (uint32_t)bytes;
 }
 
 // Most simulations one kernel launch may take.  The per-block LDS histogram counts in uint32 and a cell

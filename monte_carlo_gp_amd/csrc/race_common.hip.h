@@ -73,8 +73,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-// One 32-bit word -> N(0,1): piecewise-cubic inverse CDF (tools/gen_normal_table.py).
-__device__ __forceinline__ float normal_from_u32(uint32_t w, const float4 *__restrict__ tab)
+// One 32-bit word -> N(0,1): piecewise-cubic inverse CDF (tools/gen_normal_table.py).  `row(k)` returns the
+// k-th coefficient row as a float4.
+template <typename RowFn>
+__device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
 {
     const uint32_t m = w & 0x7fffffffu;
     const bool small = m < 16u;
@@ -85,11 +87,16 @@ __device__ __forceinline__ float normal_from_u32(uint32_t w, const float4 *__res
     float t = ((float)r + 0.5f) * __uint_as_float((uint32_t)(127 - sh) << 23);
     t = small ? 0.0f : t;
     const uint32_t row = small ? m : 16u + 16u * (uint32_t)sh + k;
-    const float4 c = tab[row];
+    const float4 c = row_of(row);
     float z = __builtin_fmaf(c.w, t, c.z);
     z = __builtin_fmaf(z, t, c.y);
     z = __builtin_fmaf(z, t, c.x);
     return (w >> 31) ? -z : z;
+}
+
+__device__ __forceinline__ float normal_from_u32(uint32_t w, const float4 *__restrict__ tab)
+{
+    return normal_from_u32_rows(w, [tab](uint32_t row) -> float4 { return tab[row]; });
 }
 
 __device__ __forceinline__ double u32_to_unit(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }

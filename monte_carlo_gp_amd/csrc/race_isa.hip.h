@@ -15,5 +15,269 @@ __device__ __forceinline__ void minmax_f64(double a, double b, double &lo, doubl
     asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
 }
 
+__device__ __forceinline__ double max_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Compare-exchange on the time alone, the payload word following its time: after it (ca, pa) holds the smaller
+// time.  Equal times are left as they are (stable).  One statement so that the two f64 selects sit between the
+// compare and the payload selects: the v_cmp -> v_cndmask (VCC) dependency needs two wait states, and the compiler
+// left to itself pads them with an s_nop per comparator.
+__device__ __forceinline__ void cmpx_time(double &ca, uint32_t &pa, double &cb, uint32_t &pb)
+{
+    double lo, hi;
+    uint32_t p0, p1;
+    asm("v_cmp_gt_f64 vcc, %[a], %[b]\n\t"
+        "v_min_f64 %[lo], %[a], %[b]\n\t"
+        "v_max_f64 %[hi], %[a], %[b]\n\t"
+        "v_cndmask_b32 %[p0], %[pa], %[pb], vcc\n\t"
+        "v_cndmask_b32 %[p1], %[pb], %[pa], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [p0] "=&v"(p0), [p1] "=&v"(p1)
+        : [a] "v"(ca), [b] "v"(cb), [pa] "v"(pa), [pb] "v"(pb)
+        : "vcc");
+    ca = lo; cb = hi; pa = p0; pb = p1;
+}
+
+// ---- merged comparators ----
+// hipcc pads every inline-asm statement that touches VCC with an s_nop; several comparators per statement
+// amortise it (and keep the v_cmp -> v_cndmask spacing without padding).  All are compare-exchanges on the time
+// alone with the payload word following its time, exactly cmpx_time.
+
+// two independent comparators (a1, b1) and (a2, b2)
+__device__ __forceinline__ void cmpx_time2(double &a1, uint32_t &pa1, double &b1, uint32_t &pb1,
+                                           double &a2, uint32_t &pa2, double &b2, uint32_t &pb2)
+{
+    double lo1, hi1, lo2, hi2;
+    uint32_t x1, y1, x2, y2;
+    asm(
+        "v_cmp_gt_f64 vcc, %[a1], %[b1]\n\t"
+        "v_min_f64 %[lo1], %[a1], %[b1]\n\t"
+        "v_max_f64 %[hi1], %[a1], %[b1]\n\t"
+        "v_cndmask_b32 %[x1], %[pa1], %[pb1], vcc\n\t"
+        "v_cndmask_b32 %[y1], %[pb1], %[pa1], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[a2], %[b2]\n\t"
+        "v_min_f64 %[lo2], %[a2], %[b2]\n\t"
+        "v_max_f64 %[hi2], %[a2], %[b2]\n\t"
+        "v_cndmask_b32 %[x2], %[pa2], %[pb2], vcc\n\t"
+        "v_cndmask_b32 %[y2], %[pb2], %[pa2], vcc"
+        : [lo1] "=&v"(lo1), [hi1] "=&v"(hi1), [x1] "=&v"(x1), [y1] "=&v"(y1), [lo2] "=&v"(lo2), [hi2] "=&v"(hi2),
+          [x2] "=&v"(x2), [y2] "=&v"(y2)
+        : [a1] "v"(a1), [b1] "v"(b1), [pa1] "v"(pa1), [pb1] "v"(pb1), [a2] "v"(a2), [b2] "v"(b2), [pa2] "v"(pa2),
+          [pb2] "v"(pb2)
+        : "vcc");
+    a1 = lo1; b1 = hi1; pa1 = x1; pb1 = y1;
+    a2 = lo2; b2 = hi2; pa2 = x2; pb2 = y2;
+}
+
+// forward bubble over 3 consecutive slots: comparators (0,1), (1,2), .. in sequence, the maximum ends in the last
+__device__ __forceinline__ void bubble_fwd2(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2)
+{
+    double lo1, h1, lo2, h2;
+    uint32_t q1, r1, q2, r2;
+    asm(
+        "v_cmp_gt_f64 vcc, %[c0], %[c1]\n\t"
+        "v_min_f64 %[lo1], %[c0], %[c1]\n\t"
+        "v_max_f64 %[h1], %[c0], %[c1]\n\t"
+        "v_cndmask_b32 %[q1], %[p0], %[p1], vcc\n\t"
+        "v_cndmask_b32 %[r1], %[p1], %[p0], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[h1], %[c2]\n\t"
+        "v_min_f64 %[lo2], %[h1], %[c2]\n\t"
+        "v_max_f64 %[h2], %[h1], %[c2]\n\t"
+        "v_cndmask_b32 %[q2], %[r1], %[p2], vcc\n\t"
+        "v_cndmask_b32 %[r2], %[p2], %[r1], vcc"
+        : [lo1] "=&v"(lo1), [h1] "=&v"(h1), [q1] "=&v"(q1), [r1] "=&v"(r1), [lo2] "=&v"(lo2), [h2] "=&v"(h2), [q2] "=&v"(q2), [r2] "=&v"(r2)
+        : [c0] "v"(c0), [p0] "v"(p0), [c1] "v"(c1), [p1] "v"(p1), [c2] "v"(c2), [p2] "v"(p2)
+        : "vcc");
+    c0 = lo1; p0 = q1;
+    c1 = lo2; p1 = q2;
+    c2 = h2; p2 = r2;
+}
+
+// backward bubble over 3 consecutive slots: comparators (1,2), (0,1), .. in sequence, the minimum ends in slot 0
+__device__ __forceinline__ void bubble_bwd2(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2)
+{
+    double l1, hi1, l2, hi2;
+    uint32_t q1, r1, q2, r2;
+    asm(
+        "v_cmp_gt_f64 vcc, %[c1], %[c2]\n\t"
+        "v_min_f64 %[l1], %[c1], %[c2]\n\t"
+        "v_max_f64 %[hi1], %[c1], %[c2]\n\t"
+        "v_cndmask_b32 %[q1], %[p1], %[p2], vcc\n\t"
+        "v_cndmask_b32 %[r1], %[p2], %[p1], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[c0], %[l1]\n\t"
+        "v_min_f64 %[l2], %[c0], %[l1]\n\t"
+        "v_max_f64 %[hi2], %[c0], %[l1]\n\t"
+        "v_cndmask_b32 %[q2], %[p0], %[q1], vcc\n\t"
+        "v_cndmask_b32 %[r2], %[q1], %[p0], vcc"
+        : [l1] "=&v"(l1), [hi1] "=&v"(hi1), [q1] "=&v"(q1), [r1] "=&v"(r1), [l2] "=&v"(l2), [hi2] "=&v"(hi2), [q2] "=&v"(q2), [r2] "=&v"(r2)
+        : [c0] "v"(c0), [p0] "v"(p0), [c1] "v"(c1), [p1] "v"(p1), [c2] "v"(c2), [p2] "v"(p2)
+        : "vcc");
+    c2 = hi1; p2 = r1;
+    c1 = hi2; p1 = r2;
+    c0 = l2; p0 = q2;
+}
+
+// forward bubble over 4 consecutive slots: comparators (0,1), (1,2), .. in sequence, the maximum ends in the last
+__device__ __forceinline__ void bubble_fwd3(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3)
+{
+    double lo1, h1, lo2, h2, lo3, h3;
+    uint32_t q1, r1, q2, r2, q3, r3;
+    asm(
+        "v_cmp_gt_f64 vcc, %[c0], %[c1]\n\t"
+        "v_min_f64 %[lo1], %[c0], %[c1]\n\t"
+        "v_max_f64 %[h1], %[c0], %[c1]\n\t"
+        "v_cndmask_b32 %[q1], %[p0], %[p1], vcc\n\t"
+        "v_cndmask_b32 %[r1], %[p1], %[p0], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[h1], %[c2]\n\t"
+        "v_min_f64 %[lo2], %[h1], %[c2]\n\t"
+        "v_max_f64 %[h2], %[h1], %[c2]\n\t"
+        "v_cndmask_b32 %[q2], %[r1], %[p2], vcc\n\t"
+        "v_cndmask_b32 %[r2], %[p2], %[r1], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[h2], %[c3]\n\t"
+        "v_min_f64 %[lo3], %[h2], %[c3]\n\t"
+        "v_max_f64 %[h3], %[h2], %[c3]\n\t"
+        "v_cndmask_b32 %[q3], %[r2], %[p3], vcc\n\t"
+        "v_cndmask_b32 %[r3], %[p3], %[r2], vcc"
+        : [lo1] "=&v"(lo1), [h1] "=&v"(h1), [q1] "=&v"(q1), [r1] "=&v"(r1), [lo2] "=&v"(lo2), [h2] "=&v"(h2), [q2] "=&v"(q2), [r2] "=&v"(r2), [lo3] "=&v"(lo3), [h3] "=&v"(h3), [q3] "=&v"(q3), [r3] "=&v"(r3)
+        : [c0] "v"(c0), [p0] "v"(p0), [c1] "v"(c1), [p1] "v"(p1), [c2] "v"(c2), [p2] "v"(p2), [c3] "v"(c3), [p3] "v"(p3)
+        : "vcc");
+    c0 = lo1; p0 = q1;
+    c1 = lo2; p1 = q2;
+    c2 = lo3; p2 = q3;
+    c3 = h3; p3 = r3;
+}
+
+// backward bubble over 4 consecutive slots: comparators (2,3), (1,2), .. in sequence, the minimum ends in slot 0
+__device__ __forceinline__ void bubble_bwd3(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3)
+{
+    double l1, hi1, l2, hi2, l3, hi3;
+    uint32_t q1, r1, q2, r2, q3, r3;
+    asm(
+        "v_cmp_gt_f64 vcc, %[c2], %[c3]\n\t"
+        "v_min_f64 %[l1], %[c2], %[c3]\n\t"
+        "v_max_f64 %[hi1], %[c2], %[c3]\n\t"
+        "v_cndmask_b32 %[q1], %[p2], %[p3], vcc\n\t"
+        "v_cndmask_b32 %[r1], %[p3], %[p2], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[c1], %[l1]\n\t"
+        "v_min_f64 %[l2], %[c1], %[l1]\n\t"
+        "v_max_f64 %[hi2], %[c1], %[l1]\n\t"
+        "v_cndmask_b32 %[q2], %[p1], %[q1], vcc\n\t"
+        "v_cndmask_b32 %[r2], %[q1], %[p1], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[c0], %[l2]\n\t"
+        "v_min_f64 %[l3], %[c0], %[l2]\n\t"
+        "v_max_f64 %[hi3], %[c0], %[l2]\n\t"
+        "v_cndmask_b32 %[q3], %[p0], %[q2], vcc\n\t"
+        "v_cndmask_b32 %[r3], %[q2], %[p0], vcc"
+        : [l1] "=&v"(l1), [hi1] "=&v"(hi1), [q1] "=&v"(q1), [r1] "=&v"(r1), [l2] "=&v"(l2), [hi2] "=&v"(hi2), [q2] "=&v"(q2), [r2] "=&v"(r2), [l3] "=&v"(l3), [hi3] "=&v"(hi3), [q3] "=&v"(q3), [r3] "=&v"(r3)
+        : [c0] "v"(c0), [p0] "v"(p0), [c1] "v"(c1), [p1] "v"(p1), [c2] "v"(c2), [p2] "v"(p2), [c3] "v"(c3), [p3] "v"(p3)
+        : "vcc");
+    c3 = hi1; p3 = r1;
+    c2 = hi2; p2 = r2;
+    c1 = hi3; p1 = r3;
+    c0 = l3; p0 = q3;
+}
+
+// forward bubble over 5 consecutive slots: comparators (0,1), (1,2), .. in sequence, the maximum ends in the last
+__device__ __forceinline__ void bubble_fwd4(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3, double &c4, uint32_t &p4)
+{
+    double lo1, h1, lo2, h2, lo3, h3, lo4, h4;
+    uint32_t q1, r1, q2, r2, q3, r3, q4, r4;
+    asm(
+        "v_cmp_gt_f64 vcc, %[c0], %[c1]\n\t"
+        "v_min_f64 %[lo1], %[c0], %[c1]\n\t"
+        "v_max_f64 %[h1], %[c0], %[c1]\n\t"
+        "v_cndmask_b32 %[q1], %[p0], %[p1], vcc\n\t"
+        "v_cndmask_b32 %[r1], %[p1], %[p0], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[h1], %[c2]\n\t"
+        "v_min_f64 %[lo2], %[h1], %[c2]\n\t"
+        "v_max_f64 %[h2], %[h1], %[c2]\n\t"
+        "v_cndmask_b32 %[q2], %[r1], %[p2], vcc\n\t"
+        "v_cndmask_b32 %[r2], %[p2], %[r1], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[h2], %[c3]\n\t"
+        "v_min_f64 %[lo3], %[h2], %[c3]\n\t"
+        "v_max_f64 %[h3], %[h2], %[c3]\n\t"
+        "v_cndmask_b32 %[q3], %[r2], %[p3], vcc\n\t"
+        "v_cndmask_b32 %[r3], %[p3], %[r2], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[h3], %[c4]\n\t"
+        "v_min_f64 %[lo4], %[h3], %[c4]\n\t"
+        "v_max_f64 %[h4], %[h3], %[c4]\n\t"
+        "v_cndmask_b32 %[q4], %[r3], %[p4], vcc\n\t"
+        "v_cndmask_b32 %[r4], %[p4], %[r3], vcc"
+        : [lo1] "=&v"(lo1), [h1] "=&v"(h1), [q1] "=&v"(q1), [r1] "=&v"(r1), [lo2] "=&v"(lo2), [h2] "=&v"(h2), [q2] "=&v"(q2), [r2] "=&v"(r2), [lo3] "=&v"(lo3), [h3] "=&v"(h3), [q3] "=&v"(q3), [r3] "=&v"(r3), [lo4] "=&v"(lo4), [h4] "=&v"(h4), [q4] "=&v"(q4), [r4] "=&v"(r4)
+        : [c0] "v"(c0), [p0] "v"(p0), [c1] "v"(c1), [p1] "v"(p1), [c2] "v"(c2), [p2] "v"(p2), [c3] "v"(c3), [p3] "v"(p3), [c4] "v"(c4), [p4] "v"(p4)
+        : "vcc");
+    c0 = lo1; p0 = q1;
+    c1 = lo2; p1 = q2;
+    c2 = lo3; p2 = q3;
+    c3 = lo4; p3 = q4;
+    c4 = h4; p4 = r4;
+}
+
+// backward bubble over 5 consecutive slots: comparators (3,4), (2,3), .. in sequence, the minimum ends in slot 0
+__device__ __forceinline__ void bubble_bwd4(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3, double &c4, uint32_t &p4)
+{
+    double l1, hi1, l2, hi2, l3, hi3, l4, hi4;
+    uint32_t q1, r1, q2, r2, q3, r3, q4, r4;
+    asm(
+        "v_cmp_gt_f64 vcc, %[c3], %[c4]\n\t"
+        "v_min_f64 %[l1], %[c3], %[c4]\n\t"
+        "v_max_f64 %[hi1], %[c3], %[c4]\n\t"
+        "v_cndmask_b32 %[q1], %[p3], %[p4], vcc\n\t"
+        "v_cndmask_b32 %[r1], %[p4], %[p3], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[c2], %[l1]\n\t"
+        "v_min_f64 %[l2], %[c2], %[l1]\n\t"
+        "v_max_f64 %[hi2], %[c2], %[l1]\n\t"
+        "v_cndmask_b32 %[q2], %[p2], %[q1], vcc\n\t"
+        "v_cndmask_b32 %[r2], %[q1], %[p2], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[c1], %[l2]\n\t"
+        "v_min_f64 %[l3], %[c1], %[l2]\n\t"
+        "v_max_f64 %[hi3], %[c1], %[l2]\n\t"
+        "v_cndmask_b32 %[q3], %[p1], %[q2], vcc\n\t"
+        "v_cndmask_b32 %[r3], %[q2], %[p1], vcc\n\t"
+        "v_cmp_gt_f64 vcc, %[c0], %[l3]\n\t"
+        "v_min_f64 %[l4], %[c0], %[l3]\n\t"
+        "v_max_f64 %[hi4], %[c0], %[l3]\n\t"
+        "v_cndmask_b32 %[q4], %[p0], %[q3], vcc\n\t"
+        "v_cndmask_b32 %[r4], %[q3], %[p0], vcc"
+        : [l1] "=&v"(l1), [hi1] "=&v"(hi1), [q1] "=&v"(q1), [r1] "=&v"(r1), [l2] "=&v"(l2), [hi2] "=&v"(hi2), [q2] "=&v"(q2), [r2] "=&v"(r2), [l3] "=&v"(l3), [hi3] "=&v"(hi3), [q3] "=&v"(q3), [r3] "=&v"(r3), [l4] "=&v"(l4), [hi4] "=&v"(hi4), [q4] "=&v"(q4), [r4] "=&v"(r4)
+        : [c0] "v"(c0), [p0] "v"(p0), [c1] "v"(c1), [p1] "v"(p1), [c2] "v"(c2), [p2] "v"(p2), [c3] "v"(c3), [p3] "v"(p3), [c4] "v"(c4), [p4] "v"(p4)
+        : "vcc");
+    c4 = hi1; p4 = r1;
+    c3 = hi2; p3 = r2;
+    c2 = hi3; p2 = r3;
+    c1 = hi4; p1 = r4;
+    c0 = l4; p0 = q4;
+}
+
+// LDS access by ABSOLUTE byte address.  The register kernel declares no static __shared__ data, so its
+// dynamic LDS block starts at address 0 (checked once at kernel entry); addressing it by number instead of
+// through the `extern __shared__` symbol lets the compiler fold every table / row base into the 16-bit
+// immediate offset of the ds_read / ds_write instead of adding the (symbolic) base in a VALU instruction.
+#define MCGP_LDS __attribute__((address_space(3)))
+template <typename T>
+__device__ __forceinline__ T lds_ld(uint32_t addr)
+{
+    return *reinterpret_cast<const MCGP_LDS T *>(addr);
+}
+template <typename T>
+__device__ __forceinline__ void lds_st(uint32_t addr, T v)
+{
+    *reinterpret_cast<MCGP_LDS T *>(addr) = v;
+}
+__device__ __forceinline__ float4 lds_ld_float4(uint32_t addr)          // one ds_read_b128
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = *reinterpret_cast<const MCGP_LDS v4f *>(addr);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// address of the dynamic LDS block as the hardware sees it
+__device__ __forceinline__ uint32_t lds_base_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const MCGP_LDS void *)p;
+}
+
 }  // namespace mcgp
 #endif

@@ -5,20 +5,23 @@
 // simulation live in VGPR arrays indexed by TIME RANK over all cars
 //
 //     cum[r]  f64   cumulative time of the car at rank r      (reference CarState.cumulative_time)
-//     pk[r]   u32   grid slot | driver | dirty | drs | dnf | used compounds | compound | tyre age
+//     pk[r]   u32   grid slot | tyre age | driver | compound | dirty | drs | dnf | dry compounds used
 //
 // Every loop over cars is fully unrolled, so all register indices are compile-time
 // constants; "the car ahead" is simply rank r-1.  Ordering work is a fixed compare-exchange
 // network (Knuth's merge exchange, 97 comparators for N = 20) on (cum, pk) after the lap
-// times have been added, and odd-even transposition rounds after an overtake pass (which
-// only perturbs the order locally).  Ties compare pk as an integer: the grid slot sits in
-// its top bits, which is Python's stable-sort order for the reference's grid-ordered lists.
+// times have been added, and one forward + one backward bubble pass after an overtake pass
+// (which only moves a few cars by 0.1-0.3 s).  Ties compare pk as an integer: the grid slot sits
+// in its top bits, which is Python's stable-sort order for the reference's grid-ordered lists.
 //
-// LDS holds only what must be addressed by DRIVER index per lane (conflict-free, row stride
-// = blockDim.x): last lap time [driver] f64, this lap's deviates [driver] f32 (NaN = the DNF
-// draw hit), later re-used for the overtake draw words; plus the block-shared tables.
-// 12 N + 16 bytes per simulation instead of 21 N: 8 waves per CU instead of 5, and no LDS
-// round trip on the hot per-car state.
+// The block size is a compile-time function of N (RegGeo<N>::B), so every LDS address is
+// "bit field of pk | lane offset" + an immediate:
+//   per-lane rows (row stride = B: bank = f(lane) only, conflict-free gathers by driver index)
+//     Z    [N + 4][B] u32   this lap's deviate per DRIVER (NaN = the DNF draw hit); later the overtake draw words
+//     LAST [N][B]     f64   last lap time per DRIVER                 (reference CarState.last_lap_time)
+//   block-shared tables: inverse-normal cubic, per-driver {variance, base pace, degradation},
+//     per-(driver, compound) {degradation x factor, pit threshold}, per-compound pace delta,
+//     the n x n histogram (u32) and the transposed grid matrix.
 //
 // Random draws: one Philox block per TWO drivers and lap (words: dnf, noise, dnf, noise),
 // generated in a driver-indexed pre-pass with wave-uniform thresholds, so the per-lap RNG
@@ -37,50 +40,112 @@
 #define MCGP_SKIP 0
 #endif
 
-
 #include <utility>
 
 namespace mcgp {
 
-// pk word of the register kernel
-constexpr uint32_t k2AgeMask = 0x7FFu;         // tyre age; lap of retirement once dnf is set
-constexpr int k2CompShift = 11;                // 3 bits
-constexpr int k2UsedShift = 14;                // 5 bits
-constexpr uint32_t k2Dnf = 1u << 19;
-constexpr uint32_t k2Drs = 1u << 20;
-constexpr uint32_t k2Dirty = 1u << 21;
-constexpr int k2IdShift = 22;                  // 5 bits, driver index
-constexpr int k2GposShift = 27;                // 5 bits, grid slot (most significant: tie-break)
+// pk word of the register kernel.  Field positions are chosen so that LDS addresses fall out of one
+// mask or one shift + mask: (pk & 0x7C00) = driver << 10 = the byte offset of the driver's Z row when
+// B = 256; (pk >> 6) & 0x1F0 = 16 driver; (pk & 0x380) << 2 = 512 compound; (pk >> 3) & 0x70 = 16 compound;
+// pk & 0x10 = 16 drs.
+constexpr uint32_t k3UsedMask = 7u;            // [0..2] dry compounds used so far (SOFT, MEDIUM, HARD)
+constexpr uint32_t k3Drs = 1u << 4;            // (pk & 0x10) = 16 drs: byte offset into the {0.0, drs_delta} table
+constexpr uint32_t k3Dirty = 1u << 5;          // 0 < time_behind_leader < dirty_air_threshold
+constexpr int k3CompShift = 7;                 // [7..9]   tyre compound
+constexpr uint32_t k3CompMask = 7u << k3CompShift;
+constexpr int k3IdShift = 10;                  // [10..14] driver index
+constexpr uint32_t k3IdMask = 31u << k3IdShift;
+constexpr uint32_t k3Dnf = 1u << 15;           // directly above the driver index: (pk >> 6) & 0x3F0 = 16 (32 dnf + driver)
+constexpr int k3AgeShift = 16;                 // [16..26] tyre age; lap of retirement once dnf is set
+constexpr uint32_t k3AgeMask = 0x7FFu << k3AgeShift;
+constexpr int k3GposShift = 27;                // [27..31] grid slot (most significant: tie-break)
 
-__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)n * 12 + 16; }
-// block-shared tables of the register kernel: normal table, per-driver / per-compound constants,
-// n x n histogram (u32) and the transposed grid-probability matrix [slot][driver] (f64)
+// ---- launch geometry and LDS map, fixed per field size ----
+constexpr size_t kLdsPerCu = 160 * 1024;       // gfx950
+__host__ __device__ constexpr size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)(n + 4) * 4 + (size_t)n * 8; }
+// block-shared tables: inverse-normal rows, per-driver {var, base} and {base, deg} (the latter with a second
+// half of NaNs that the pk word of a RETIRED car indexes: its pace is NaN, so both pairs it belongs to fail
+// every overtake test without a flag test), per-(compound, driver) {eff f64, opt u32, pad} for the 5 compounds,
+// per-compound {delta, pad}, {0.0, drs_delta}, n x n histogram (u32), transposed grid matrix (f64).  The driver
+// index varies fastest in every table (16-byte entries): lanes holding different drivers hit different banks,
+// the same driver broadcasts.
+constexpr int kNumCompounds = 5;
 __host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
 {
-    return (size_t)kNormalRows * 16 + 4 * kMaxCars * 8 + kMaxCars * 8 + 2 * kCompStride * 8 +
-           kMaxCars * kCompStride * 2 + (((size_t)n * n * 4 + 15) / 16) * 16 + (size_t)n * n * 8;
+    return (size_t)kNormalRows * 16 + 3 * (size_t)kMaxCars * 16 + (size_t)kNumCompounds * kMaxCars * 16 +
+           kCompStride * 16 + 32 + align16((size_t)n * n * 4) + (size_t)n * n * 8;
+}
+// Waves per block: the (waves per block, blocks per CU) pair that keeps the most waves resident within the
+// LDS budget at the kernel's 2 waves per SIMD (8 per CU); among equals at least 4 waves per block (fewer
+// copies of the shared tables), then the smaller block.
+__host__ __device__ constexpr int reg_block_waves(int n)
+{
+    int best = 0, waves = 1;
+    for (int w = 1; w <= 8; ++w) {
+        int b = (int)(kLdsPerCu / (shared_lds_bytes_reg(n) + (size_t)w * 64 * per_thread_lds_bytes_reg(n)));
+        if (b * w > 8) b = 8 / w;
+        if (b >= 1 && (b * w > best || (b * w == best && waves < 4))) { best = b * w; waves = w; }
+    }
+    return waves;
 }
 
-// Knuth, TAOCP 5.2.2 Algorithm M (merge exchange): a sorting network for any N.
+template <int N>
+struct RegGeo {
+    static constexpr int kWaves = reg_block_waves(N);
+    static constexpr int B = 64 * kWaves;                         // threads per block
+    // block-shared tables first: their bases (and the row bases below) fit the 16-bit immediate offset of a DS
+    // instruction, so an address is just the bit field taken from pk
+    static constexpr uint32_t oNorm = 0;                          // float4[kNormalRows]
+    static constexpr uint32_t oDrvA = oNorm + kNormalRows * 16;   // {var, base} x 32 drivers, 16 B each   (lap step)
+    static constexpr uint32_t oDrvB = oDrvA + kMaxCars * 16;      // {base, deg} x 32 drivers + 32 x {NaN, NaN}  (overtake pace)
+    static constexpr uint32_t oIc = oDrvB + 2 * kMaxCars * 16;    // [compound][driver] {eff f64, opt u32, pad}, 16 B each
+    static constexpr uint32_t oComp = oIc + kNumCompounds * kMaxCars * 16;   // {delta f64, pad} x 8, 16 B each
+    static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}
+    static constexpr uint32_t oHist = oDrs + 32;                  // u32[N x N]
+    static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
+    static constexpr uint32_t oZ = oGrid + N * N * 8;             // [N + 4][B] u32
+    static constexpr uint32_t oLast = oZ + (uint32_t)(N + 4) * B * 4;  // [N][B] f64
+    static constexpr uint32_t kBytes = oLast + (uint32_t)N * B * 8;
+    static_assert(oZ == shared_lds_bytes_reg(N) && oLast % 8 == 0, "LDS map");
+    static_assert(kBytes == per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N), "LDS map");
+    static_assert(kBytes <= kLdsPerCu, "block does not fit LDS");
+    // (oLast < 65536 for N <= 20: the row bases then fit the DS immediate offset as well)
+};
+
+// Knuth, TAOCP 5.2.2 Algorithm M (merge exchange): a sorting network for any N.  Comparators of one (p, q, r, d)
+// step touch disjoint slots; they are grouped two by two (ga / gn) so that two go into one instruction block.
 template <int N>
 struct MergeExchange {
     int a[N * 8];
     int b[N * 8];
+    int step[N * 8];
     int n;
-    constexpr MergeExchange() : a{}, b{}, n(0)
+    int ga[N * 8];          // group -> index of its first comparator
+    int gn[N * 8];          // group -> 1 or 2 comparators
+    int n_groups;
+    constexpr MergeExchange() : a{}, b{}, step{}, n(0), ga{}, gn{}, n_groups(0)
     {
-        int t = 0;
+        int t = 0, s = 0;
         while ((1 << t) < N) ++t;
         for (int p = t > 0 ? 1 << (t - 1) : 0; p > 0; p >>= 1) {
             int q = 1 << (t - 1), r = 0, d = p;
             while (true) {
                 for (int i = 0; i < N - d; ++i)
-                    if ((i & p) == r) { a[n] = i; b[n] = i + d; ++n; }
+                    if ((i & p) == r) { a[n] = i; b[n] = i + d; step[n] = s; ++n; }
+                ++s;
                 if (q == p) break;
                 d = q - p;
                 q >>= 1;
                 r = p;
             }
+        }
+        for (int i = 0; i < n;) {
+            const int len = (i + 1 < n && step[i + 1] == step[i]) ? 2 : 1;
+            ga[n_groups] = i;
+            gn[n_groups] = len;
+            ++n_groups;
+            i += len;
         }
     }
 };
@@ -96,32 +161,57 @@ __device__ __forceinline__ bool cmpx(double &ca, uint32_t &pa, double &cb, uint3
     return sw;
 }
 
-// compare-exchange on the time alone (ties left as they are): the network's comparator.
-__device__ __forceinline__ void cmpx_time(double &ca, uint32_t &pa, double &cb, uint32_t &pb)
-{
-    const bool sw = ca > cb;
-    double c0, c1;
-    minmax_f64(ca, cb, c0, c1);
-    const uint32_t p0 = sw ? pb : pa, p1 = sw ? pa : pb;
-    ca = c0; cb = c1; pa = p0; pb = p1;
-}
+// cmpx_time(ca, pa, cb, pb): compare-exchange on the time alone (ties left as they are), race_isa.hip.h.
 
-template <int N, size_t... I>
-__device__ __forceinline__ void network_sort_impl(double (&cum)[N], uint32_t (&pk)[N], std::index_sequence<I...>)
+template <int N, int G>
+__device__ __forceinline__ void network_group(double (&cum)[N], uint32_t (&pk)[N])
 {
     constexpr MergeExchange<N> net{};
-    (cmpx_time(cum[net.a[I]], pk[net.a[I]], cum[net.b[I]], pk[net.b[I]]), ...);
+    constexpr int i = net.ga[G];
+    if constexpr (net.gn[G] == 2)
+        cmpx_time2(cum[net.a[i]], pk[net.a[i]], cum[net.b[i]], pk[net.b[i]],
+                   cum[net.a[i + 1]], pk[net.a[i + 1]], cum[net.b[i + 1]], pk[net.b[i + 1]]);
+    else
+        cmpx_time(cum[net.a[i]], pk[net.a[i]], cum[net.b[i]], pk[net.b[i]]);
 }
 
-// Is the field in (cumulative_time, grid slot) order?
-template <int N>
-__device__ __forceinline__ bool in_order(const double (&cum)[N], const uint32_t (&pk)[N])
+template <int N, size_t... G>
+__device__ __forceinline__ void network_sort_impl(double (&cum)[N], uint32_t (&pk)[N], std::index_sequence<G...>)
 {
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i + 1 < N; ++i)
-        bad |= (cum[i] > cum[i + 1]) || (cum[i] == cum[i + 1] && pk[i] > pk[i + 1]);
-    return !bad;
+    (network_group<N, (int)G>(cum, pk), ...);
+}
+
+// Forward bubble pass from slot I: comparators (I, I+1), (I+1, I+2), .. (N-2, N-1), four to an instruction block.
+template <int N, int I>
+__device__ __forceinline__ void bubble_forward(double (&c)[N], uint32_t (&p)[N])
+{
+    constexpr int left = N - 1 - I;
+    if constexpr (left >= 4) {
+        bubble_fwd4(c[I], p[I], c[I + 1], p[I + 1], c[I + 2], p[I + 2], c[I + 3], p[I + 3], c[I + 4], p[I + 4]);
+        bubble_forward<N, I + 4>(c, p);
+    } else if constexpr (left == 3) {
+        bubble_fwd3(c[I], p[I], c[I + 1], p[I + 1], c[I + 2], p[I + 2], c[I + 3], p[I + 3]);
+    } else if constexpr (left == 2) {
+        bubble_fwd2(c[I], p[I], c[I + 1], p[I + 1], c[I + 2], p[I + 2]);
+    } else if constexpr (left == 1) {
+        cmpx_time(c[I], p[I], c[I + 1], p[I + 1]);
+    }
+}
+
+// Backward bubble pass: comparators (T-1, T), (T-2, T-1), .. (0, 1).
+template <int N, int T>
+__device__ __forceinline__ void bubble_backward(double (&c)[N], uint32_t (&p)[N])
+{
+    if constexpr (T >= 4) {
+        bubble_bwd4(c[T - 4], p[T - 4], c[T - 3], p[T - 3], c[T - 2], p[T - 2], c[T - 1], p[T - 1], c[T], p[T]);
+        bubble_backward<N, T - 4>(c, p);
+    } else if constexpr (T == 3) {
+        bubble_bwd3(c[0], p[0], c[1], p[1], c[2], p[2], c[3], p[3]);
+    } else if constexpr (T == 2) {
+        bubble_bwd2(c[0], p[0], c[1], p[1], c[2], p[2]);
+    } else if constexpr (T == 1) {
+        cmpx_time(c[0], p[0], c[1], p[1]);
+    }
 }
 
 // After a round that ends with the odd pairs (1,2), (3,4), .. those pairs are in order by
@@ -136,8 +226,9 @@ __device__ __forceinline__ bool even_pairs_in_order(const double (&cum)[N], cons
     return !bad;
 }
 
-// Odd-even transposition rounds until the field is in order: the re-sort after a LOCAL
-// perturbation (an overtake pass moves a few cars by 0.1-0.3 s).
+// Odd-even transposition rounds with the full (time, grid slot) comparator until the field is in
+// order: the general re-sort, correct for any input.  Rarely reached (equal times, or a disturbance
+// the cheaper passes below did not undo).
 template <int N>
 __device__ __forceinline__ void transposition_sort(double (&cum)[N], uint32_t (&pk)[N])
 {
@@ -147,6 +238,28 @@ __device__ __forceinline__ void transposition_sort(double (&cum)[N], uint32_t (&
 #pragma unroll
         for (int i = 1; i + 1 < N; i += 2) (void)cmpx(cum[i], pk[i], cum[i + 1], pk[i + 1]);
     } while (!even_pairs_in_order<N>(cum, pk));
+}
+
+// Is the field in (time, grid slot) order?  One pass over the adjacent pairs.
+template <int N>
+__device__ __forceinline__ bool in_order(const double (&cum)[N], const uint32_t (&pk)[N])
+{
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i + 1 < N; ++i)
+        bad |= (cum[i] > cum[i + 1]) || (cum[i] == cum[i + 1] && pk[i] > pk[i + 1]);
+    return !bad;
+}
+
+// Strictly increasing times: the field is in order whatever the tie-break says (one compare per pair).
+// The cheap test; when it fails (an inversion, or two equal times) the exact, tie-aware code takes over.
+template <int N>
+__device__ __forceinline__ bool strictly_increasing(const double (&cum)[N])
+{
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i + 1 < N; ++i) bad |= !(cum[i] < cum[i + 1]);
+    return !bad;
 }
 
 // After the time-only network the field is ordered by time; only equal times can still be in the
@@ -161,14 +274,33 @@ __device__ __forceinline__ bool ties_in_order(const double (&cum)[N], const uint
 }
 
 // Full sort by (cumulative_time, grid slot): Python's stable sorted() of the reference (:506 etc.).
-// The network orders by time; equal times (structural: lap-1 retirements at 0.0) are then put in
-// grid order by the transposition rounds, which almost never have anything to do.
+// The network orders by time; equal times are then put in grid order by the transposition rounds, which
+// almost never have anything to do (the structural ties of the reference, lap-1 retirements at 0.0, are
+// kept apart by the representation chosen in lap 1, see there).
 template <int N>
 __device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N])
 {
     constexpr MergeExchange<N> net{};
-    network_sort_impl<N>(cum, pk, std::make_index_sequence<(size_t)net.n>{});
-    if (!ties_in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
+    network_sort_impl<N>(cum, pk, std::make_index_sequence<(size_t)net.n_groups>{});
+    if (__builtin_expect(!strictly_increasing<N>(cum), 0)) {
+        if (!ties_in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
+    }
+}
+
+// Re-sort after an overtake pass.  The pass moved a few cars: the overtaken one back by 0.2 s, the
+// overtaking one to 0.1 s ahead of where its rival was.  One forward bubble pass carries every car
+// that fell back to its place, one backward pass every car that moved up; time-only comparators
+// (5 instructions instead of 9) never swap equal times, so ties keep their (correct) relative order.
+// The result is then CHECKED with the full (time, grid slot) order and anything left -- cars crossing
+// each other, a new exact tie in the wrong grid order -- goes to the general re-sort.
+template <int N>
+__device__ __forceinline__ void resort_after_overtakes(double (&cum)[N], uint32_t (&pk)[N])
+{
+    bubble_forward<N, 0>(cum, pk);                 // (0,1), (1,2), .. (N-2,N-1)
+    bubble_backward<N, N - 2>(cum, pk);            // (N-3,N-2), .. (0,1): the last slot already holds the maximum
+    if (__builtin_expect(!strictly_increasing<N>(cum), 0)) {
+        if (!in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
+    }
 }
 
 // _update_positions, reference :538-560.
@@ -181,17 +313,43 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         uint32_t p = pk[i];
-        if (!(p & k2Dnf)) {
+        if (!(p & k3Dnf)) {
             const double t = cum[i];
             if (first) leader = t;
             const double tbl = t - leader;
-            p &= ~(k2Drs | k2Dirty);
-            if (tbl > 0 && tbl < dirty_thr) p |= k2Dirty;
-            if (!first && drs_allowed && (t - prev) < 1.0) p |= k2Drs;
+            p &= ~(k3Drs | k3Dirty);
+            if (tbl > 0 && tbl < dirty_thr) p |= k3Dirty;
+            if (!first && drs_allowed && (t - prev) < 1.0) p |= k3Drs;
             pk[i] = p;
             prev = t;
             first = false;
         }
+    }
+}
+
+// Compound fitted at a pit stop (reference :469-490) as a function of the dry compounds already used
+// (3 bits) -- everything else it depends on is the same for the whole wave in a given lap, so the
+// rule is evaluated 8 times on the scalar unit and packed 3 bits per entry:
+//   lut_comp  bits [3u..3u+2] = new compound,  lut_used bits [3u..3u+2] = dry compounds used afterwards
+__device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uint32_t pop_sh, uint32_t pop_mh,
+                                              uint32_t &lut_comp, uint32_t &lut_used)
+{
+    lut_comp = 0u;
+    lut_used = 0u;
+    const uint32_t stint = stint_compound(track, remaining_laps);
+#pragma unroll
+    for (uint32_t used = 0; used < 8; ++used) {
+        uint32_t newc = stint;
+        // two-compound rule, dry races only (:481-490): exactly one dry compound used so far and the
+        // stint rule would fit it again -> take another one
+        if (track == 0 && __builtin_popcount(used) == 1 && ((used >> newc) & 1u)) {
+            const uint32_t avail = 7u & ~used;
+            const uint32_t popped = avail == 5u ? pop_sh : avail == 6u ? pop_mh : 0u;
+            if (remaining_laps > 20) newc = (avail & 2u) ? 1u : popped;
+            else newc = (avail & 1u) ? 0u : popped;
+        }
+        lut_comp |= newc << (3 * used);
+        lut_used |= ((used | (1u << newc)) & 7u) << (3 * used);
     }
 }
 
@@ -201,57 +359,98 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
 #ifndef MCGP_PREPASS_BLOCKS
 #define MCGP_PREPASS_BLOCKS 2
 #endif
+#ifndef MCGP_STEP_BATCH
+#define MCGP_STEP_BATCH 5          // slots whose LDS gathers are in flight together in the lap step
+#endif
+
+// Phase 1 of a block: fill the block-shared LDS tables (all threads, strided).
 template <int N>
-__global__ void __launch_bounds__(512, MCGP_MIN_WAVES)
-race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
-                uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
-                uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
+__device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int B = blockDim.x;
-    const int L = P->total_laps;
-    const int track = P->track;
-
-    // ---- LDS carve-up: block-shared tables, then the per-lane rows ----
-    float4 *t_norm = reinterpret_cast<float4 *>(smem);
-    double *t_base = reinterpret_cast<double *>(smem + kNormalRows * 16);
-    double *t_factor = t_base + kMaxCars;
-    double *t_deg = t_factor + kMaxCars;
-    double *t_var = t_deg + kMaxCars;
-    unsigned long long *t_dnf = reinterpret_cast<unsigned long long *>(t_var + kMaxCars);
-    double *t_cdeg = reinterpret_cast<double *>(t_dnf + kMaxCars);
-    double *t_cdelta = t_cdeg + kCompStride;
-    uint16_t *t_opt = reinterpret_cast<uint16_t *>(t_cdelta + kCompStride);
-    uint32_t *s_hist = reinterpret_cast<uint32_t *>(t_opt + kMaxCars * kCompStride);
-    double *t_grid = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(s_hist) + ((N * N * 4 + 15) / 16) * 16);  // [slot][driver]
-    double *s_last = t_grid + N * N;                                               // [driver][lane]
-    uint32_t *s_word = reinterpret_cast<uint32_t *>(s_last + (size_t)N * B);       // [N + 4][lane]
-    float *s_z = reinterpret_cast<float *>(s_word);
-
-#define LAST(d) s_last[(d) * B + tid]
-#define ZED(d) s_z[(d) * B + tid]
-#define WORD(k) s_word[(k) * B + tid]
-
-    for (int i = tid; i < kNormalRows * 4; i += B)
+    using G = RegGeo<N>;
+    constexpr int B = G::B;
+    float4 *t_norm = reinterpret_cast<float4 *>(smem + G::oNorm);
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + G::oHist);
+    double *t_grid = reinterpret_cast<double *>(smem + G::oGrid);          // [slot][driver]
+    for (uint32_t i = tid; i < (uint32_t)kNormalRows * 4; i += B)
         reinterpret_cast<uint32_t *>(t_norm)[i] = P->normal_bits[i];
-    for (int i = tid; i < kMaxCars; i += B) {
-        t_base[i] = P->base_pace[i];
-        t_factor[i] = P->factor[i];
-        t_deg[i] = P->tire_deg[i];
-        t_var[i] = P->variance[i];
-        t_dnf[i] = P->t_dnf[i];
+    for (uint32_t d = tid; d < (uint32_t)kMaxCars; d += B) {
+        double *a = reinterpret_cast<double *>(smem + G::oDrvA + d * 16);
+        double *b = reinterpret_cast<double *>(smem + G::oDrvB + d * 16);
+        const double qnan = __builtin_nan("");
+        a[0] = d < (uint32_t)N ? P->variance[d] : 0.0;
+        a[1] = d < (uint32_t)N ? P->base_pace[d] : 0.0;
+        b[0] = d < (uint32_t)N ? P->base_pace[d] : 0.0;
+        b[1] = d < (uint32_t)N ? P->tire_deg[d] : 0.0;
+        b[2 * kMaxCars] = qnan;                                  // the retired half: pace = NaN
+        b[2 * kMaxCars + 1] = qnan;
     }
-    for (int i = tid; i < kCompStride; i += B) {
-        t_cdeg[i] = P->comp_deg[i];
-        t_cdelta[i] = P->comp_delta[i];
+    if (tid < 2) {
+        double *r = reinterpret_cast<double *>(smem + G::oDrs + tid * 16);
+        r[0] = tid ? P->drs_delta : 0.0;
+        r[1] = 0.0;
     }
-    for (int i = tid; i < kMaxCars * kCompStride; i += B) t_opt[i] = P->opt_laps[i];
-    for (int i = tid; i < N * N; i += B) {
+    for (uint32_t i = tid; i < (uint32_t)kNumCompounds * N; i += B) {
+        const uint32_t c = i / N, d = i % N;
+        unsigned char *r = smem + G::oIc + (c * kMaxCars + d) * 16;
+        // degradation per lap of tyre age: compound rate x driver factor, reference :319-322
+        *reinterpret_cast<double *>(r) = P->comp_deg[c] * P->factor[d];
+        *reinterpret_cast<uint32_t *>(r + 8) = P->opt_laps[d * kCompStride + c];
+        *reinterpret_cast<uint32_t *>(r + 12) = 0u;
+    }
+    for (uint32_t c = tid; c < (uint32_t)kCompStride; c += B) {
+        double *r = reinterpret_cast<double *>(smem + G::oComp + c * 16);
+        r[0] = P->comp_delta[c];
+        r[1] = 0.0;
+    }
+    for (uint32_t i = tid; i < (uint32_t)(N * N); i += B) {
         s_hist[i] = 0u;
         t_grid[(i % N) * N + (i / N)] = P->grid_probs[i];       // transposed: lanes gather by driver, conflict-free
     }
-    __syncthreads();
+}
+
+// Phase 3 of a block: add the block's histogram to the global one (reference :93-94 summed over the block).
+template <int N>
+__device__ __forceinline__ void reg_flush_hist(unsigned char *smem, uint32_t tid, unsigned long long *__restrict__ hist)
+{
+    using G = RegGeo<N>;
+    const uint32_t *s_hist = reinterpret_cast<const uint32_t *>(smem + G::oHist);
+    for (uint32_t i = tid; i < (uint32_t)(N * N); i += G::B) {
+        const uint32_t c = s_hist[i];
+        if (c) atomicAdd(&hist[i], (unsigned long long)c);
+    }
+}
+
+// Phase 2: this lane's simulations (batches block_index, block_index + n_blocks, ...), one full race each.
+template <int N>
+__device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid,
+                                             uint32_t block_index, uint32_t n_blocks, uint64_t n_sims,
+                                             uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
+                                             uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid,
+                                             uint32_t n_batches)
+{
+    using G = RegGeo<N>;
+    constexpr int B = G::B;
+    const uint32_t tid4 = tid * 4u, tid8 = tid * 8u;
+    const int L = P->total_laps;
+    const int track = P->track;
+
+    // ---- typed views of the LDS map (RegGeo) for the cold paths (grid sampling, histogram) ----
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + G::oHist);
+    double *t_grid = reinterpret_cast<double *>(smem + G::oGrid);          // [slot][driver]
+
+    // per-lane rows by ABSOLUTE LDS address (race_isa.hip.h): a compile-time row is an immediate offset ...
+    auto z_row = [&](int d) -> uint32_t { return G::oZ + (uint32_t)d * (B * 4) + tid4; };
+    auto l_row = [&](int d) -> uint32_t { return G::oLast + (uint32_t)d * (B * 8) + tid8; };
+    // ... and the row of the driver held in a pk word is one and-or (B = 256); the f64 row sits at twice that offset
+    auto row4 = [&](uint32_t p) -> uint32_t {
+        if constexpr (B == 256) return (p & k3IdMask) | tid4;
+        else if constexpr (B == 512) return ((p & k3IdMask) << 1) | tid4;
+        else if constexpr (B == 128) return ((p & k3IdMask) >> 1) | tid4;
+        else if constexpr (B == 64) return ((p & k3IdMask) >> 2) | tid4;
+        else return ((p >> k3IdShift) & 31u) * (uint32_t)(B * 4) + tid4;
+    };
+    auto norm_row = [&](uint32_t row) -> float4 { return lds_ld_float4(G::oNorm + row * 16u); };
 
     const double pit_loss = P->pit_loss;
     const double overtake_delta = P->overtake_delta;
@@ -262,28 +461,30 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     const uint32_t pop_sh = (uint32_t)P->pop_sh, pop_mh = (uint32_t)P->pop_mh;
     const uint64_t t_red = P->t_red, t_sc = P->t_sc, t_vsc = P->t_vsc, t_vsc_tire = P->t_vsc_tire;
 
-    // Everything the lap step of one slot reads from LDS, fetched in one batch.
+    // Everything the lap step of one slot reads from LDS.
     struct SlotIn {
         float z;
         uint32_t opt;
-        double last, base, factor, var, cdeg, cdelta;
+        double last, var, base, eff, cdelta, drs;
+        uint32_t a4;            // byte offset of the driver's Z row (the LAST row is at twice that)
     };
     auto load_slot = [&](uint32_t p) -> SlotIn {
-        const uint32_t id = (p >> k2IdShift) & 31u;
-        const uint32_t comp = (p >> k2CompShift) & 7u;
         SlotIn r;
-        r.z = ZED(id);
-        r.last = LAST(id);
-        r.base = t_base[id];
-        r.factor = t_factor[id];
-        r.var = t_var[id];
-        r.cdeg = t_cdeg[comp];
-        r.cdelta = t_cdelta[comp];
-        r.opt = t_opt[id * kCompStride + comp];
+        r.a4 = row4(p);
+        r.z = lds_ld<float>(G::oZ + r.a4);
+        r.last = lds_ld<double>(G::oLast + (r.a4 << 1));
+        const uint32_t id16 = (p >> 6) & 0x1F0u;                                  // 16 x driver
+        const uint32_t ic = id16 + ((p & k3CompMask) << 2);                       // 16 x (32 compound + driver)
+        r.var = lds_ld<double>(G::oDrvA + id16);
+        r.base = lds_ld<double>(G::oDrvA + 8 + id16);
+        r.eff = lds_ld<double>(G::oIc + ic);
+        r.opt = lds_ld<uint32_t>(G::oIc + 8 + ic);
+        r.cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));                 // 16 x compound
+        r.drs = lds_ld<double>(G::oDrs + (p & k3Drs));                            // 0.0 or drs_delta
         return r;
     };
 
-    for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+    for (uint32_t batch = block_index; batch < n_batches; batch += n_blocks) {
         const uint64_t local = (uint64_t)batch * (uint64_t)B + (uint64_t)tid;
         if (local >= n_sims) continue;
         const uint64_t sim = sim_offset + local;
@@ -319,7 +520,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     for (uint32_t m = remaining; m; m &= m - 1u) {
                         const int d = __ffs((int)m) - 1;
                         const double p = total > 0 ? gcol[d] / total : 1.0 / (double)n_remaining;
-                        LAST(d) = p;
+                        lds_st<double>(l_row(d), p);
                         prob_sum = prob_sum + p;
                     }
                     const bool renorm = prob_sum > 0 && fabs(prob_sum - 1.0) > 1e-9;   // :134-135
@@ -327,73 +528,79 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     double acc = 0.0;
                     for (uint32_t m = remaining; m; m &= m - 1u) {
                         const int d = __ffs((int)m) - 1;
-                        double p = LAST(d);
+                        double p = lds_ld<double>(l_row(d));
                         if (renorm) p = p / prob_sum;
                         acc = acc + p;
-                        LAST(d) = acc;
+                        lds_st<double>(l_row(d), acc);
                     }
                     const double cdf_last = acc;
                     sel = (uint32_t)N;
                     for (uint32_t m = remaining; m; m &= m - 1u) {        // first driver whose cdf exceeds u
                         const int d = __ffs((int)m) - 1;
-                        if (sel == (uint32_t)N && !(LAST(d) / cdf_last <= u)) sel = (uint32_t)d;
+                        if (sel == (uint32_t)N && !(lds_ld<double>(l_row(d)) / cdf_last <= u)) sel = (uint32_t)d;
                     }
                     if (sel >= (uint32_t)N) sel = 31u - (uint32_t)__clz((int)remaining);   // unreachable: cdf[-1] == 1 > u
                 }
                 if ((remaining >> sel) & 1u) { remaining &= ~(1u << sel); --n_remaining; }
-                WORD(pos) = sel;
+                lds_st<uint32_t>(z_row(pos), sel);
             }
         }
 
         // ================= _initialize_cars, reference :244-273 (slot i = grid position i) =================
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const uint32_t id = WORD(i);
+            const uint32_t id = lds_ld<uint32_t>(z_row(i));
             uint32_t comp, age;
             if (track == 2) { comp = 4u; age = 0u; }
             else if (track == 1) { comp = 3u; age = 0u; }
             else { comp = i < 10 ? 0u : 1u; age = i < 10 ? 4u : 0u; }
-            pk[i] = age | (comp << k2CompShift) | ((1u << comp) << k2UsedShift) | (id << k2IdShift) |
-                    ((uint32_t)i << k2GposShift);
+            pk[i] = (age << k3AgeShift) | (comp << k3CompShift) | ((1u << comp) & k3UsedMask) | (id << k3IdShift) |
+                    ((uint32_t)i << k3GposShift);
             cum[i] = 0.0;
         }
 
         // ================= _simulate_lap_1, reference :275-311 =================
-        // draws by driver (wave-uniform thresholds): ZED = lap-noise deviate or NaN (retired), LAST = start deviate
+        // draws by driver (wave-uniform thresholds): Z = lap-noise deviate or NaN (retired), LAST = start deviate
 #pragma unroll 1
         for (int d = 0; d < N; ++d) {
             uint32_t w0, w1, w2, w3;
             philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
             const bool out = (uint64_t)w0 < P->t_dnf1[d];
-            ZED(d) = out ? kNaN : normal_from_u32(w1, t_norm);
-            LAST(d) = (double)normal_from_u32(w2, t_norm);
+            lds_st<float>(z_row(d), out ? kNaN : normal_from_u32_rows(w1, norm_row));
+            lds_st<double>(l_row(d), (double)normal_from_u32_rows(w2, norm_row));
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const uint32_t p = pk[i];
-            const uint32_t id = (p >> k2IdShift) & 31u;
-            const float z = ZED(id);
-            const double zs = LAST(id);
+            const SlotIn s = load_slot(p);
+            const float z = s.z;
+            const double zs = s.last;
             if (z != z) {
-                pk[i] = (p & ~k2AgeMask) | k2Dnf | 1u;
+                pk[i] = (p & ~k3AgeMask) | k3Dnf | (1u << k3AgeShift);
+                // The reference leaves a lap-1 retirement at cumulative_time 0.0, so several of them tie; ties sort
+                // in grid order.  Here the car on grid slot i is given -(i + 1) * 2^-1000 instead: still below every
+                // running car's time, never equal to anything, and among themselves in the order the only consumer
+                // of their relative order wants -- the classification sorts retirements of one lap by time
+                // DESCENDING, i.e. grid slot ascending, exactly the reference's stable tie.  (Overtakes, events and
+                // _update_positions skip retired cars; nothing else reads these values.)  Keeping them apart lets
+                // "strictly increasing times" be the sortedness test of the hot loop.
+                cum[i] = -(double)(i + 1) * 0x1p-1000;
             } else {
-                const uint32_t comp = (p >> k2CompShift) & 7u;
-                const uint32_t age = p & k2AgeMask;
-                const double eff = t_cdeg[comp] * t_factor[id];
-                const double tire = (double)age * eff;
+                const uint32_t age = (p >> k3AgeShift) & 0x7FFu;
+                const double tire = (double)age * s.eff;
                 const double fuel_effect = (110.0 - 110.0) * 0.03;
-                const double noise = 0.0 + t_var[id] * (double)z;
-                const double base_lap = t_base[id] + tire - fuel_effect + t_cdelta[comp] - 0.0 + noise;
+                const double noise = 0.0 + s.var * (double)z;
+                const double base_lap = s.base + tire - fuel_effect + s.cdelta - 0.0 + noise;
                 double pf = 0.5 + (double)(i + 1) * 0.1;
                 if (!(pf < 1.5)) pf = 1.5;
                 double sd = 0.0 + pf * zs;
                 if (i + 1 <= 3 && 1.0 < sd) sd = 1.0;
                 cum[i] = 0.0 + (base_lap - sd * 0.5);
-                pk[i] = (p & ~k2AgeMask) | (age + 1u);
+                pk[i] = p + (1u << k3AgeShift);
             }
         }
 #pragma unroll 1
-        for (int d = 0; d < N; ++d) LAST(d) = 0.0;          // last_lap_time is not set on lap 1 (Q3)
+        for (int d = 0; d < N; ++d) lds_st<double>(l_row(d), 0.0);          // last_lap_time is not set on lap 1 (Q3)
         network_sort<N>(cum, pk);
         update_positions_reg<N>(cum, pk, false, dirty_thr);
 
@@ -423,7 +630,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
                         uint32_t p = pk[i];
-                        if (!(p & k2Dnf)) {
+                        if (!(p & k3Dnf)) {
                             const double t = cum[i];
                             if (k == 0) leader = t;
                             double nt;
@@ -433,17 +640,17 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                             tie |= nt == prev_nt;
                             prev_nt = nt;
                             const double tbl = nt - leader;
-                            p &= ~k2Dirty;
-                            if (tbl > 0 && tbl < dirty_thr) p |= k2Dirty;
-                            uint32_t age = p & k2AgeMask;
+                            p &= ~k3Dirty;
+                            if (tbl > 0 && tbl < dirty_thr) p |= k3Dirty;
+                            uint32_t age = (p >> k3AgeShift) & 0x7FFu;
                             if (red) {
                                 age = 0u;
-                                p = (p & ~(7u << k2CompShift)) | (newc << k2CompShift) | ((1u << newc) << k2UsedShift);
+                                p = (p & ~k3CompMask) | (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
                             } else if (dec_age) {
                                 age = age > 0u ? age - 1u : 0u;
                             }
                             cum[i] = nt;
-                            pk[i] = (p & ~k2AgeMask) | age;
+                            pk[i] = (p & ~k3AgeMask) | (age << k3AgeShift);
                             ++k;
                         }
                     }
@@ -475,75 +682,72 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
 #pragma unroll
                 for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
                     const int d0 = 2 * (b0 + j), d1 = d0 + 1;
-                    z[j][0] = normal_from_u32(w[j][1], t_norm);
-                    z[j][1] = normal_from_u32(w[j][3], t_norm);
-                    q[j][0] = t_dnf[d0 < N ? d0 : 0];
-                    q[j][1] = t_dnf[d1 < N ? d1 : 0];
+                    z[j][0] = normal_from_u32_rows(w[j][1], norm_row);
+                    z[j][1] = normal_from_u32_rows(w[j][3], norm_row);
+                    q[j][0] = P->t_dnf[d0 < N ? d0 : 0];              // wave-uniform: scalar loads
+                    q[j][1] = P->t_dnf[d1 < N ? d1 : 0];
                 }
 #pragma unroll
                 for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
                     const int d0 = 2 * (b0 + j), d1 = d0 + 1;
-                    if (d0 < N) ZED(d0) = ((uint64_t)w[j][0] < q[j][0]) ? kNaN : z[j][0];
-                    if (d1 < N) ZED(d1) = ((uint64_t)w[j][2] < q[j][1]) ? kNaN : z[j][1];
+                    if (d0 < N) lds_st<float>(z_row(d0), ((uint64_t)w[j][0] < q[j][0]) ? kNaN : z[j][0]);
+                    if (d1 < N) lds_st<float>(z_row(d1), ((uint64_t)w[j][2] < q[j][1]) ? kNaN : z[j][1]);
                 }
             }
 
             // ---- every running car's lap (:179-223) with its pit stop (:433-494), in time-rank order ----
-            // All LDS gathers of a slot (deviate, last lap, per-driver and per-compound constants) are issued
-            // in one batch, one slot ahead of their use, so the wave does not park on s_waitcnt per access.
+            // Written without branches: every slot computes its lap and the results are merged by selects, so the
+            // LDS gathers of MCGP_STEP_BATCH slots stay in flight together (nothing can be sunk into a branch) and
+            // the wave does not pay exec-mask bookkeeping per car.  What a retired car "computes" is discarded:
+            // +0.0 on its time, its pk kept, and a LAST value nobody reads (only running cars feed `carry`).
             {
                 double fuel = 110.0 - 1.5 * (double)(lap - 1);
                 if (!(fuel > 0)) fuel = 0.0;
                 const double fuel_effect = (110.0 - fuel) * 0.03;
+                const bool pit_window = remaining_laps > 5;                                     // :451
+                uint32_t lut_comp, lut_used;
+                pit_rule_luts(track, remaining_laps, pop_sh, pop_mh, lut_comp, lut_used);
+                const uint32_t retire_bits = k3Dnf | ((uint32_t)lap << k3AgeShift);
                 double carry = 0.0;
-                SlotIn cur = load_slot(pk[0]);
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    SlotIn nxt = cur;
-                    if (i + 1 < N) nxt = load_slot(pk[i + 1]);
-                    uint32_t p = pk[i];
-                    if (!(p & k2Dnf)) {
-                        const uint32_t id = (p >> k2IdShift) & 31u;
-                        const double ahead_last = carry;
-                        carry = cur.last;
-                        const float z = cur.z;
-                        if (z != z) {
-                            pk[i] = (p & ~k2AgeMask) | k2Dnf | (uint32_t)lap;
-                        } else {
-                            uint32_t comp = (p >> k2CompShift) & 7u;
-                            uint32_t age = p & k2AgeMask;
-                            const double eff = cur.cdeg * cur.factor;
-                            const double tire = (double)age * eff;
-                            const double drs_gain = (p & k2Drs) ? drs_delta : 0.0;
-                            const double noise = 0.0 + cur.var * (double)z;
-                            const double clean = cur.base + tire - fuel_effect + cur.cdelta - drs_gain + noise;
-                            double lap_time = clean;
-                            if ((p & k2Dirty) && ahead_last > 0) {
-                                const double dirty_time = clean + dirty_pen;
-                                lap_time = ahead_last > dirty_time ? ahead_last : dirty_time;
-                            }
-                            double t = cum[i] + lap_time;
-                            age += 1u;
-                            if ((int)age > (int)cur.opt && remaining_laps > 5) {
-                                t = t + pit_loss;
-                                uint32_t newc = stint_compound(track, remaining_laps);
-                                const uint32_t used_dry = (p >> k2UsedShift) & 7u;
-                                if (track == 0 && __popc(used_dry) == 1 && ((used_dry >> newc) & 1u)) {
-                                    const uint32_t avail = 7u & ~used_dry;
-                                    const uint32_t popped = avail == 5u ? pop_sh : avail == 6u ? pop_mh : 0u;
-                                    if (remaining_laps > 20) newc = (avail & 2u) ? 1u : popped;
-                                    else newc = (avail & 1u) ? 0u : popped;
-                                }
-                                comp = newc;
-                                p = (p & ~(7u << k2CompShift)) | (comp << k2CompShift) | ((1u << comp) << k2UsedShift);
-                                age = 0u;
-                            }
-                            cum[i] = t;
-                            LAST(id) = lap_time;
-                            pk[i] = (p & ~k2AgeMask) | age;
-                        }
+                for (int i0 = 0; i0 < N; i0 += MCGP_STEP_BATCH) {
+                    SlotIn in[MCGP_STEP_BATCH];
+#pragma unroll
+                    for (int j = 0; j < MCGP_STEP_BATCH; ++j)
+                        if (i0 + j < N) in[j] = load_slot(pk[i0 + j]);
+#pragma unroll
+                    for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
+                        const int i = i0 + j;
+                        if (i >= N) continue;
+                        const SlotIn &s = in[j];
+                        const uint32_t p = pk[i];
+                        const bool active = !(p & k3Dnf);                   // running at the start of the lap
+                        const bool retire = active && (s.z != s.z);         // this lap's DNF draw hit   :194-197
+                        const bool run = active && !(s.z != s.z);
+                        const double ahead_last = carry;                    // last lap of the running car ahead  :179-183
+                        carry = active ? s.last : carry;
+                        const uint32_t age = (p >> k3AgeShift) & 0x7FFu;
+                        const double tire = (double)age * s.eff;                                   // :319-322
+                        const double drs_gain = s.drs;                                              // :327
+                        const double noise = 0.0 + s.var * (double)s.z;                             // :330
+                        const double clean = s.base + tire - fuel_effect + s.cdelta - drs_gain + noise;   // :332
+                        const double dirty_time = clean + dirty_pen;                                // :213
+                        const double held = ahead_last > dirty_time ? ahead_last : dirty_time;       // :215
+                        const bool in_dirty = (p & k3Dirty) && ahead_last > 0;                      // :209-212
+                        const double lap_time = in_dirty ? held : clean;
+                        // pit stop (:450-492): compound and used-set from the per-lap rule tables
+                        const bool pit = run && pit_window && (int)(age + 1u) > (int)s.opt;
+                        const uint32_t u3 = (p & k3UsedMask) * 3u;
+                        const uint32_t newc = (lut_comp >> u3) & 7u, newu = (lut_used >> u3) & 7u;
+                        const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | (newc << k3CompShift) | newu;
+                        const uint32_t p_run = pit ? p_pit : p + (1u << k3AgeShift);
+                        const uint32_t p_ret = (p & ~k3AgeMask) | retire_bits;
+                        pk[i] = run ? p_run : retire ? p_ret : p;
+                        // x + 0.0 == x for the finite, non-negative times here: cars that do not run keep their time
+                        const double t = cum[i] + (run ? lap_time : 0.0);
+                        cum[i] = t + (pit ? pit_loss : 0.0);                                        // :464
+                        lds_st<double>(G::oLast + (s.a4 << 1), lap_time);                                                      // :219
                     }
-                    cur = nxt;
                 }
             }
 
@@ -552,6 +756,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
             if (MCGP_DUP & 1) network_sort<N>(cum, pk);
 #pragma unroll 1
             for (int pass = 0; pass < ((MCGP_SKIP & 1) ? 0 : 3); ++pass) {
+                // ---- overtakes: pace deltas and candidates ----
                 // pace of every slot (:514-515) and the pace delta of every adjacent pair.  The per-driver
                 // constants are gathered half a field at a time (one s_waitcnt per half, not per slot).
                 double delta[N];
@@ -561,25 +766,26 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     double pace_prev = 0.0;
 #pragma unroll
                     for (int h = 0; h < N; h += H) {
-                        double pb[H], pd[H];
+                        double pb[H], pd[H], pa[H];
 #pragma unroll
                         for (int j = 0; j < H; ++j) {
                             if (h + j < N) {
-                                const uint32_t id = (pk[h + j] >> k2IdShift) & 31u;
-                                pb[j] = t_base[id];
-                                pd[j] = t_deg[id];
+                                const uint32_t id16 = (pk[h + j] >> 6) & 0x3F0u;      // 16 x (32 dnf + driver)
+                                pb[j] = lds_ld<double>(G::oDrvB + id16);
+                                pd[j] = lds_ld<double>(G::oDrvB + 8 + id16);
+                                pa[j] = lds_ld<double>(G::oDrs + (pk[h + j] & k3Drs));
                             }
                         }
 #pragma unroll
                         for (int j = 0; j < H; ++j) {
                             const int i = h + j;
                             if (i < N) {
-                                const double pace = pb[j] + (double)(pk[i] & k2AgeMask) * pd[j];
+                                // a retired car's pace is NaN (table): its two pairs compare false below (:511)
+                                const double pace = pb[j] + (double)((pk[i] >> k3AgeShift) & 0x7FFu) * pd[j];
                                 if (i > 0) {
-                                    double dl = pace_prev - pace;                                   // :516
-                                    if (pk[i] & k2Drs) dl += drs_delta;                             // :519-520
+                                    const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520
                                     delta[i] = dl;
-                                    if (!((pk[i] | pk[i - 1]) & k2Dnf) && dl > overtake_delta) cand |= 1u << i;   // :511,522
+                                    if (dl > overtake_delta) cand |= 1u << i;                       // :522
                                 }
                                 pace_prev = pace;
                             }
@@ -587,6 +793,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     }
                 }
                 if (cand == 0u) break;
+                // ---- overtakes: draw words ----
                 // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4
                 const int n_cand = __popc(cand);
 #pragma unroll 1
@@ -594,88 +801,99 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                     uint32_t o0, o1, o2, o3;
                     philox4x32_10(c0, c1, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + b), seed_lo, seed_hi,
                                   o0, o1, o2, o3);
-                    WORD(4 * b + 0) = o0;
-                    WORD(4 * b + 1) = o1;
-                    WORD(4 * b + 2) = o2;
-                    WORD(4 * b + 3) = o3;
+                    lds_st<uint32_t>(z_row(4 * b + 0), o0);
+                    lds_st<uint32_t>(z_row(4 * b + 1), o1);
+                    lds_st<uint32_t>(z_row(4 * b + 2), o2);
+                    lds_st<uint32_t>(z_row(4 * b + 3), o3);
                 }
+                // ---- overtakes: which attempts succeed ----
                 // which attempts succeed (:523-524) does not depend on the times: all draw words are
                 // fetched in one batch and compared before the sequential write-back chain
                 uint32_t ow[N];
 #pragma unroll
-                for (int i = 1; i < N; ++i) ow[i] = WORD(__popc(cand & ((1u << i) - 1u)));
-                uint32_t succ = 0u;
+                for (int i = 1; i < N; ++i)
+                    ow[i] = lds_ld<uint32_t>(G::oZ + (uint32_t)__popc(cand & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4);
+                // ---- overtakes: success test and write-back chain ----
+                // :523-531 in sorted order, each pair seeing the previous pair's mutation (Q15).  Branch-free: the
+                // new times of a pair are computed for every slot and committed by selects under the success mask.
+                bool any_succ = false;
 #pragma unroll
                 for (int i = 1; i < N; ++i) {
                     // u < min(0.5, delta / 2)  <=>  w < 2^31  and  w * 2^-31 < delta   (u = w * 2^-32, exact scalings)
-                    const bool hit = ow[i] < 0x80000000u && (double)ow[i] * (1.0 / 2147483648.0) < delta[i];
-                    if (((cand >> i) & 1u) && hit) succ |= 1u << i;
+                    const bool hit = ((cand >> i) & 1u) && ow[i] < 0x80000000u &&
+                                     (double)ow[i] * (1.0 / 2147483648.0) < delta[i];
+                    const double nb = max_f64(cum[i - 1] - 0.1, 0.1);          // max(0.1, ahead - 0.1), :528
+                    const double na = nb + 0.3;                                // :530
+                    cum[i] = hit ? nb : cum[i];
+                    cum[i - 1] = hit ? na : cum[i - 1];
+                    any_succ |= hit;
                 }
-                if (succ == 0u) break;
-                // :525-531, in sorted order, each pair seeing the previous pair's mutation (Q15)
-#pragma unroll
-                for (int i = 1; i < N; ++i) {
-                    if ((succ >> i) & 1u) {
-                        double nb = cum[i - 1] - 0.1;
-                        if (!(nb > 0.1)) nb = 0.1;
-                        cum[i] = nb;
-                        cum[i - 1] = nb + 0.3;
-                    }
-                }
-                transposition_sort<N>(cum, pk);     // sorted again for the next pass / _update_positions
-                if (MCGP_DUP & 8) transposition_sort<N>(cum, pk);
+                if (!any_succ) break;
+                // ---- overtakes: re-sort ----
+                resort_after_overtakes<N>(cum, pk);     // sorted again for the next pass / _update_positions
+                if (MCGP_DUP & 8) resort_after_overtakes<N>(cum, pk);
             }
-            update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);   // :227-228
+            // ---- _update_positions, :227-228 ----
+            update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
             if (MCGP_DUP & 4) update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
         }
 
         // ================= classification, reference :230-242 =================
-        // rows to LDS (cum -> LAST rows, pk -> WORD rows), insertion sort with the classification
+        // rows to LDS (cum -> LAST rows, pk -> W rows), insertion sort with the classification
         // order: running cars by time, then retired cars by (lap, time) descending, stable.
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            LAST(i) = cum[i];
-            WORD(i) = pk[i];
+            lds_st<double>(l_row(i), cum[i]);
+            lds_st<uint32_t>(z_row(i), pk[i]);
         }
 #pragma unroll 1
         for (int i = 1; i < N; ++i) {
-            const uint32_t pkx = WORD(i);
-            const double kx = LAST(i);
+            const uint32_t pkx = lds_ld<uint32_t>(z_row(i));
+            const double kx = lds_ld<double>(l_row(i));
             int j = i;
             while (j > 0) {
-                const uint32_t pky = WORD(j - 1);
-                const double ky = LAST(j - 1);
+                const uint32_t pky = lds_ld<uint32_t>(z_row(j - 1));
+                const double ky = lds_ld<double>(l_row(j - 1));
                 bool y_after_x;
-                if (!(pky & k2Dnf)) y_after_x = false;            // runners are already in order and ahead of retirees
-                else if (!(pkx & k2Dnf)) y_after_x = true;
+                if (!(pky & k3Dnf)) y_after_x = false;            // runners are already in order and ahead of retirees
+                else if (!(pkx & k3Dnf)) y_after_x = true;
                 else {
-                    const uint32_t ly = pky & k2AgeMask, lx = pkx & k2AgeMask;
+                    const uint32_t ly = pky & k3AgeMask, lx = pkx & k3AgeMask;
                     y_after_x = ly < lx || (ly == lx && (ky < kx || (ky == kx && pky > pkx)));
                 }
                 if (!y_after_x) break;
-                WORD(j) = pky;
-                LAST(j) = ky;
+                lds_st<uint32_t>(z_row(j), pky);
+                lds_st<double>(l_row(j), ky);
                 --j;
             }
-            WORD(j) = pkx;
-            LAST(j) = kx;
+            lds_st<uint32_t>(z_row(j), pkx);
+            lds_st<double>(l_row(j), kx);
         }
 #pragma unroll 1
         for (int p = 0; p < N; ++p) {
-            const uint32_t d = (WORD(p) >> k2IdShift) & 31u;
+            const uint32_t d = (lds_ld<uint32_t>(z_row(p)) >> k3IdShift) & 31u;
             atomicAdd(&s_hist[d * N + p], 1u);                       // reference :93-94
             if (orders) orders[local * (uint64_t)N + (uint64_t)p] = (uint8_t)d;
         }
     }
 
+}
+
+template <int N>
+__global__ void __launch_bounds__(RegGeo<N>::B, MCGP_MIN_WAVES)
+race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
+                uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
+                uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    // host and kernel must agree on the geometry; the rows are addressed by absolute LDS address (race_isa.hip.h)
+    if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) return;
+    reg_load_tables<N>(P, smem, threadIdx.x);
     __syncthreads();
-    for (int i = tid; i < N * N; i += B) {
-        const uint32_t c = s_hist[i];
-        if (c) atomicAdd(&hist[i], (unsigned long long)c);
-    }
-#undef LAST
-#undef ZED
-#undef WORD
+    reg_simulate<N>(P, smem, threadIdx.x, blockIdx.x, gridDim.x, n_sims, sim_offset, seed_lo, seed_hi, orders,
+                    fixed_grid, n_batches);
+    __syncthreads();
+    reg_flush_hist<N>(smem, threadIdx.x, hist);
 }
 
 }  // namespace mcgp

@@ -1,7 +1,8 @@
 // emu_kernel.cpp -- DEBUGGING build of the register kernel's source for the host (not product code, not a
 // fallback: nothing in monte_carlo_gp_amd/ can reach it).  Compiles csrc/race_kernel_reg.hip.h with g++ through
-// the stand-in <hip/hip_runtime.h> of this directory and runs it one "thread" at a time (blockDim.x == 1), so a
-// kernel edit can be compared with the oracle on the CPU before a GPU run.  tests/test_kernel_host_build.py.
+// the stand-in <hip/hip_runtime.h> of this directory and runs the kernel's three phases (load tables, simulate,
+// flush) for the threads of one block one after another, so a kernel edit can be compared with the oracle on
+// the CPU before a GPU run.  tests/test_kernel_host_build.py.
 //   g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Itools/emu -o tools/emu/libmcgp_emu.so tools/emu/emu_kernel.cpp
 #include "race_isa_host.h"
 
@@ -32,11 +33,18 @@ extern "C" int emu_run(const mcgp_config *cfg, const mcgp_drivers *drv, const do
     blockDim = {1, 1, 1};
     gridDim = {1, 1, 1};
     switch (n) {
-#define X(N_)                                                                                                   \
-    case N_:                                                                                                    \
-        mcgp::race_kernel_reg<N_>(&kp, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32), hist, orders, \
-                                  fixed_grid, (uint32_t)n_sims);                                                \
-        return 0;
+#define X(N_)                                                                                                      \
+    case N_: {                                                                                                     \
+        /* one block at a time; inside a block the three phases of the kernel run for every "thread" in turn */   \
+        constexpr uint32_t B = mcgp::RegGeo<N_>::B;                                                                \
+        const uint32_t n_batches = (uint32_t)((n_sims + B - 1) / B);                                               \
+        for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N_>(&kp, mcgp::smem, t);                            \
+        for (uint32_t t = 0; t < B; ++t)                                                                           \
+            mcgp::reg_simulate<N_>(&kp, mcgp::smem, t, 0u, 1u, n_sims, sim_offset, (uint32_t)seed,                 \
+                                   (uint32_t)(seed >> 32), orders, fixed_grid, n_batches);                         \
+        for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N_>(mcgp::smem, t, hist);                            \
+        return 0;                                                                                                  \
+    }
         EMU_SIZES(X)
 #undef X
         default:

@@ -1,7 +1,7 @@
 // hip/hip_runtime.h -- HOST stand-in used ONLY by tools/emu (a debugging build of the kernel sources for the CPU).
 // It lets csrc/race_kernel_reg.hip.h compile with g++ so that a kernel edit can be checked against the oracle in
-// seconds before it is sent to a GPU.  Execution model: ONE thread per "block" (blockDim.x == 1), blocks run one
-// after another; __syncthreads() is then a no-op and LDS is a plain array.  Nothing under monte_carlo_gp_amd/
+// seconds before it is sent to a GPU.  Execution model: the threads of ONE block run one after another, phase by
+// phase (tools/emu/emu_kernel.cpp); __syncthreads() is a no-op and LDS is a plain array.  Nothing under monte_carlo_gp_amd/
 // includes or links this: the product has no CPU path.
 #pragma once
 #include <cmath>

@@ -8,5 +8,70 @@ inline void minmax_f64(double a, double b, double &lo, double &hi)
     lo = a < b ? a : b;       // times are finite, non-negative: identical to v_min_f64 / v_max_f64
     hi = a < b ? b : a;
 }
+inline double max_f64(double a, double b) { return a < b ? b : a; }
+inline void cmpx_time(double &ca, uint32_t &pa, double &cb, uint32_t &pb)
+{
+    if (ca > cb) {
+        const double t = ca; ca = cb; cb = t;
+        const uint32_t q = pa; pa = pb; pb = q;
+    }
+}
+inline void cmpx_time2(double &a1, uint32_t &pa1, double &b1, uint32_t &pb1, double &a2, uint32_t &pa2, double &b2, uint32_t &pb2)
+{
+    cmpx_time(a1, pa1, b1, pb1);
+    cmpx_time(a2, pa2, b2, pb2);
+}
+inline void bubble_fwd2(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2)
+{
+    cmpx_time(c0, p0, c1, p1);
+    cmpx_time(c1, p1, c2, p2);
+}
+inline void bubble_bwd2(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2)
+{
+    cmpx_time(c1, p1, c2, p2);
+    cmpx_time(c0, p0, c1, p1);
+}
+inline void bubble_fwd3(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3)
+{
+    cmpx_time(c0, p0, c1, p1);
+    cmpx_time(c1, p1, c2, p2);
+    cmpx_time(c2, p2, c3, p3);
+}
+inline void bubble_bwd3(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3)
+{
+    cmpx_time(c2, p2, c3, p3);
+    cmpx_time(c1, p1, c2, p2);
+    cmpx_time(c0, p0, c1, p1);
+}
+inline void bubble_fwd4(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3, double &c4, uint32_t &p4)
+{
+    cmpx_time(c0, p0, c1, p1);
+    cmpx_time(c1, p1, c2, p2);
+    cmpx_time(c2, p2, c3, p3);
+    cmpx_time(c3, p3, c4, p4);
+}
+inline void bubble_bwd4(double &c0, uint32_t &p0, double &c1, uint32_t &p1, double &c2, uint32_t &p2, double &c3, uint32_t &p3, double &c4, uint32_t &p4)
+{
+    cmpx_time(c3, p3, c4, p4);
+    cmpx_time(c2, p2, c3, p3);
+    cmpx_time(c1, p1, c2, p2);
+    cmpx_time(c0, p0, c1, p1);
+}
+// LDS by absolute byte address: the emulated LDS block is the array mcgp::smem
+extern unsigned char smem[];
+template <typename T>
+inline T lds_ld(uint32_t addr)
+{
+    T v;
+    std::memcpy(&v, smem + addr, sizeof(T));
+    return v;
+}
+template <typename T>
+inline void lds_st(uint32_t addr, T v)
+{
+    std::memcpy(smem + addr, &v, sizeof(T));
+}
+inline float4 lds_ld_float4(uint32_t addr) { return lds_ld<float4>(addr); }
+inline uint32_t lds_base_of(const void *p) { return (uint32_t)((const unsigned char *)p - smem); }
 }  // namespace mcgp
 #endif

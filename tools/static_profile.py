@@ -1,36 +1,46 @@
 #!/usr/bin/env python3
-"""Static instruction attribution of the register kernel: VALU / SALU / LDS instruction counts per source region.
+"""Static instruction attribution of the register kernel (N = 20): VALU / SALU / LDS counts per source region.
 
-    hipcc ... -gline-tables-only -S --cuda-device-only -o reg20_lines.s reg_inst.hip
-    python tools/static_profile.py reg20_lines.s
+    python tools/static_profile.py            # compiles reg_inst.hip with -gline-tables-only and prints the table
 
-Each machine instruction is attributed to the innermost race_kernel_reg.hip.h line of its .loc (inlined callees in
-race_common.hip.h are attributed through the inlined-at chain when present, else to their own file) and the lines
-are grouped into the kernel's sections.  Counts are STATIC (one per instruction in the listing): rolled loops
-(the RNG pre-pass, the overtake pass loop) count once.  Not product code.
+Every machine instruction of the listing is attributed to the source line of its .loc; lines of
+race_kernel_reg.hip.h are grouped by the `// @region name` markers found in that file (helpers above the
+kernel are grouped by function).  Counts are STATIC: rolled loops (RNG pre-pass, overtake pass loop) count once.
+Not product code.
 """
 import collections
+import os
 import re
+import subprocess
 import sys
 
-SECTIONS = [            # (first line, label) in race_kernel_reg.hip.h, ascending
-    (0, 'prologue / tables'),
-]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'monte_carlo_gp_amd', 'csrc')
+SRC = os.path.join(CSRC, 'race_kernel_reg.hip.h')
+
+
+def regions():
+    marks = [(0, 'top')]
+    for i, line in enumerate(open(SRC), 1):
+        m = re.search(r'__device__ __forceinline__ \w[\w<> ]* (\w+)\(', line)
+        if m:
+            marks.append((i, 'fn ' + m.group(1)))
+        m = re.search(r'// =+ (.+?) =+\s*$', line) or re.search(r'// ---- (.+?) ----\s*$', line)
+        if m and i > 340:
+            marks.append((i, m.group(1)[:52]))
+    return marks
 
 
 def main():
-    path = sys.argv[1]
-    src = sys.argv[2] if len(sys.argv) > 2 else 'monte_carlo_gp_amd/csrc/race_kernel_reg.hip.h'
-    marks = []
-    for i, line in enumerate(open(src), 1):
-        m = re.search(r'// @section (.+)$', line)
-        if m:
-            marks.append((i, m.group(1).strip()))
-    files = {}
-    cur = (None, 0)
-    counts = collections.defaultdict(lambda: collections.Counter())
-    ops = collections.defaultdict(lambda: collections.Counter())
-    for line in open(path):
+    n = sys.argv[1] if len(sys.argv) > 1 else '20'
+    out = f'/tmp/reg{n}_lines.s'
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off',
+                           '-fno-fast-math', '-gline-tables-only', f'-DMCGP_INST_N={n}', '-S', '--cuda-device-only',
+                           '-o', out, os.path.join(CSRC, 'reg_inst.hip')], stderr=subprocess.DEVNULL)
+    marks = regions()
+    files, cur = {}, (None, 0)
+    counts = collections.OrderedDict()
+    for line in open(out):
         s = line.strip()
         m = re.match(r'\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', s)
         if m:
@@ -39,6 +49,10 @@ def main():
         m = re.match(r'\.loc\s+(\d+)\s+(\d+)', s)
         if m:
             cur = (files.get(int(m.group(1)), '?'), int(m.group(2)))
+            # inlined-at chain: attribute to the line inside reg_simulate (the frame just below the __global__ kernel)
+            chain = re.findall(r'race_kernel_reg\.hip\.h:(\d+):', s)
+            if len(chain) >= 2:
+                cur = ('race_kernel_reg.hip.h', int(chain[-2]))
             continue
         m = re.match(r'(v_|s_|ds_|global_|buffer_|flat_)(\w+)', s)
         if not m:
@@ -49,24 +63,20 @@ def main():
             kind = 'CTRL'
         f, ln = cur
         if f and f.endswith('race_kernel_reg.hip.h'):
-            sec = 'before first mark'
-            for first, label in marks:
-                if ln >= first:
-                    sec = label
+            sec = [label for first, label in marks if ln >= first][-1]
+        elif f and f.endswith('race_common.hip.h'):
+            sec = 'race_common: philox' if 56 <= ln <= 74 else 'race_common: normal_from_u32' if 76 <= ln <= 93 else 'race_common: other'
+        elif f and f.endswith('race_isa.hip.h'):
+            sec = 'race_isa: v_min_f64 / v_max_f64'
         else:
-            sec = f'[{f}]'
-        counts[sec][kind] += 1
-        ops[sec][op.split('_e32')[0].split('_e64')[0]] += 1
+            sec = f'[{os.path.basename(f or "?")}]'
+        counts.setdefault(sec, collections.Counter())[kind] += 1
     tot = collections.Counter()
-    print(f'{"section":58s} {"VALU":>6s} {"SALU":>6s} {"LDS":>5s} {"CTRL":>5s}')
-    for sec, c in counts.items():
-        print(f'{sec:58s} {c["VALU"]:6d} {c["SALU"]:6d} {c["LDS"]:5d} {c["CTRL"]:5d}')
+    print(f'{"region":62s} {"VALU":>6s} {"SALU":>6s} {"LDS":>5s} {"CTRL":>5s}')
+    for sec, c in sorted(counts.items(), key=lambda kv: -kv[1]['VALU']):
+        print(f'{sec:62s} {c["VALU"]:6d} {c["SALU"]:6d} {c["LDS"]:5d} {c["CTRL"]:5d}')
         tot.update(c)
-    print(f'{"TOTAL":58s} {tot["VALU"]:6d} {tot["SALU"]:6d} {tot["LDS"]:5d} {tot["CTRL"]:5d}')
-    if '-v' in sys.argv:
-        for sec, c in ops.items():
-            print('\n##', sec)
-            print('   ' + ', '.join(f'{k} {v}' for k, v in c.most_common(14)))
+    print(f'{"TOTAL":62s} {tot["VALU"]:6d} {tot["SALU"]:6d} {tot["LDS"]:5d} {tot["CTRL"]:5d}')
 
 
 if __name__ == '__main__':
