@@ -122,6 +122,27 @@ int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, cons
                            uint32_t n, uint64_t sim_id, uint64_t seed, int32_t device,
                            uint8_t *order_out);
 
+/* Grid-probability front end on the device ("next" row f3): the n x n matrix [driver][grid slot] that
+ * F1Predictor._predict_quali + _adjust_for_penalties build from the Elo quali ratings
+ * (reference src/elo.py:124-141 softmax; src/predictor.py:321-375 teammate / form / circuit adjustments and the
+ * Gaussian bump around (1 - p) n; :377-407 penalty shift).  Inputs are arrays of length n in driver order with the
+ * reference's .get() defaults resolved by the caller (rating: ratings.get(d).get('quali', 1500); features: 0;
+ * penalty: grid positions, strings already mapped through PENALTY_TYPES).  exp() is the front end's own
+ * (csrc/frontend_exp.h): results agree with the reference's numpy matrices to ~1e-15 relative and are
+ * bit-identical to the CPU oracle's restatement of the same text.
+ *   mcgp_grid_probs        host arrays in, host matrix out (n x n doubles)
+ *   mcgp_run_from_ratings  run_monte_carlo with the matrix produced ON THE DEVICE, written by the front-end
+ *                          kernel straight into the race kernel's parameter block (no host round trip);
+ *                          hist_out as in mcgp_run, grid_probs_out optional (NULL to skip). */
+int32_t mcgp_grid_probs(const double *quali_rating, const double *teammate_delta, const double *form_score,
+                        const double *circuit_affinity, const int32_t *penalty, uint32_t n, int32_t device,
+                        double *grid_probs_out);
+int32_t mcgp_run_from_ratings(const mcgp_config *cfg, const mcgp_drivers *drv, const double *quali_rating,
+                              const double *teammate_delta, const double *form_score,
+                              const double *circuit_affinity, const int32_t *penalty, uint32_t n, uint64_t n_sims,
+                              uint64_t sim_offset, uint64_t seed, int32_t device, uint64_t *hist_out,
+                              double *grid_probs_out);
+
 /* Measurement hooks (bench.py): duration in ms of the race kernel(s) of the MOST
  * RECENT mcgp_run / mcgp_run_device / mcgp_simulate_race call on `device` -- by any
  * thread: the timing events belong to the device context, not to the caller -- from

@@ -92,7 +92,8 @@ def build(force=False):
 _lib = None
 
 EXPORTS = ('mcgp_abi_version', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
-           'mcgp_simulate_race', 'mcgp_last_kernel_ms', 'mcgp_last_launch_info', 'mcgp_last_kernel_name')
+           'mcgp_simulate_race', 'mcgp_grid_probs', 'mcgp_run_from_ratings', 'mcgp_last_kernel_ms',
+           'mcgp_last_launch_info', 'mcgp_last_kernel_name')
 
 
 def lib():
@@ -117,6 +118,17 @@ def lib():
         L.mcgp_simulate_race.restype = C.c_int32
         L.mcgp_simulate_race.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), C.POINTER(C.c_uint8),
                                          C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint8)]
+        ip = C.POINTER(C.c_int32)
+        missing = [f for f in EXPORTS if not hasattr(L, f)]
+        if missing and not os.environ.get('MCGP_LIB'):          # diagnostic builds of older sources may lack entry points
+            raise McgpError(-1, f'{path} does not export {missing}')
+        if 'mcgp_grid_probs' not in missing:
+            L.mcgp_grid_probs.restype = C.c_int32
+            L.mcgp_grid_probs.argtypes = [dp, dp, dp, dp, ip, C.c_uint32, C.c_int32, dp]
+            L.mcgp_run_from_ratings.restype = C.c_int32
+            L.mcgp_run_from_ratings.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), dp, dp, dp, dp, ip,
+                                                C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
+                                                C.POINTER(C.c_uint64), dp]
         L.mcgp_last_kernel_ms.restype = C.c_int32
         L.mcgp_last_kernel_ms.argtypes = [C.c_int32, C.POINTER(C.c_float)]
         L.mcgp_last_kernel_name.restype = C.c_char_p

@@ -10,6 +10,9 @@
 #include "race_kernel.hip.h"
 #include "race_kernel_reg.hip.h"
 
+#define MCGP_FE_FN __host__ __device__ static inline
+#include "frontend_exp.h"
+
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -46,6 +49,24 @@ int fail(int code, const std::string &msg)
     X(18) X(19) X(20) X(21) X(22) X(23) X(24)
 #endif
 
+// Grid-probability front end (reference src/elo.py:124-141, src/predictor.py:321-407): one thread per driver row.
+// in = [rating | teammate_delta | form_score | circuit_affinity], n doubles each.  Thread 0 computes the n pole
+// probabilities (a sequential softmax + renormalisation in the reference's order), then every thread builds its
+// row.  out may point straight into a parameter block's grid_probs slot.
+__global__ void __launch_bounds__(mcgp::kMaxCars)
+grid_probs_kernel(const double *__restrict__ in, const int32_t *__restrict__ penalty, int n, double *__restrict__ out)
+{
+    __shared__ double pole[mcgp::kMaxCars];
+    if (threadIdx.x == 0) mcgp_fe_pole_probs(in, in + n, n, pole);
+    __syncthreads();
+    const int d = threadIdx.x;
+    if (d < n) {
+        double row[mcgp::kMaxCars], tmp[mcgp::kMaxCars];
+        mcgp_fe_grid_row(pole[d], in[2 * n + d], in[3 * n + d], penalty[d], n, row, tmp);
+        for (int s = 0; s < n; ++s) out[(size_t)d * n + s] = row[s];
+    }
+}
+
 constexpr int kParamSlots = 4;
 
 struct DeviceCtx {
@@ -68,6 +89,9 @@ struct DeviceCtx {
     unsigned long long *d_hist = nullptr;     // scratch for the host-buffer entry points
     uint8_t *d_grid = nullptr;                // fixed grid for mcgp_simulate_race
     uint8_t *d_order1 = nullptr;              // one finishing order (mcgp_simulate_race)
+    double *d_fe_in = nullptr;                // front end: 4 x 32 doubles in, 32 penalties, n x n matrix out
+    int32_t *d_fe_pen = nullptr;
+    double *d_fe_out = nullptr;
     uint8_t *d_orders = nullptr;              // staging for mcgp_run(orders_out), grown on demand, kept
     size_t d_orders_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -109,6 +133,11 @@ void release_ctx(DeviceCtx &c)
     if (c.d_hist) (void)hipFree(c.d_hist);
     if (c.d_grid) (void)hipFree(c.d_grid);
     if (c.d_order1) (void)hipFree(c.d_order1);
+    if (c.d_fe_in) (void)hipFree(c.d_fe_in);
+    if (c.d_fe_pen) (void)hipFree(c.d_fe_pen);
+    if (c.d_fe_out) (void)hipFree(c.d_fe_out);
+    c.d_fe_in = c.d_fe_out = nullptr;
+    c.d_fe_pen = nullptr;
     if (c.d_orders) (void)hipFree(c.d_orders);
     if (c.ev_start) (void)hipEventDestroy(c.ev_start);
     if (c.ev_stop) (void)hipEventDestroy(c.ev_stop);
@@ -134,6 +163,9 @@ int init_ctx_body(int device, DeviceCtx &c)
     HIP_TRY(hipMalloc(&c.d_hist, sizeof(unsigned long long) * MCGP_MAX_CARS * MCGP_MAX_CARS));
     HIP_TRY(hipMalloc(&c.d_grid, MCGP_MAX_CARS));
     HIP_TRY(hipMalloc(&c.d_order1, MCGP_MAX_CARS));
+    HIP_TRY(hipMalloc(&c.d_fe_in, sizeof(double) * 4 * MCGP_MAX_CARS));
+    HIP_TRY(hipMalloc(&c.d_fe_pen, sizeof(int32_t) * MCGP_MAX_CARS));
+    HIP_TRY(hipMalloc(&c.d_fe_out, sizeof(double) * MCGP_MAX_CARS * MCGP_MAX_CARS));
     HIP_TRY(hipEventCreate(&c.ev_start));
     HIP_TRY(hipEventCreate(&c.ev_stop));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
@@ -267,15 +299,22 @@ uint64_t max_sims_per_launch()
     return cap;
 }
 
+// Front-end inputs of one call, already on the device (c.d_fe_in / c.d_fe_pen), or null.
+struct FrontEnd {
+    bool on = false;
+};
+
 int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
-           hipStream_t stream, unsigned long long *d_hist, uint8_t *d_orders, const uint8_t *d_fixed_grid)
+           hipStream_t stream, unsigned long long *d_hist, uint8_t *d_orders, const uint8_t *d_fixed_grid,
+           const FrontEnd &fe = FrontEnd())
 {
     if (n_sims == 0) return MCGP_OK;
     bool is_reg = false;
     const KernelFn kernel = select_kernel((uint32_t)kp.n, &is_reg);
     DeviceCtx::Slot *sl = nullptr;
-    for (auto &cand : c.slot)
-        if (cand.used && std::memcmp(cand.host, &kp, sizeof(kp)) == 0) { sl = &cand; break; }
+    if (!fe.on)           // a block whose matrix is written by the device front end is never shared
+        for (auto &cand : c.slot)
+            if (cand.used && std::memcmp(cand.host, &kp, sizeof(kp)) == 0) { sl = &cand; break; }
     if (!sl) {
         sl = &c.slot[c.next_slot];
         c.next_slot = (c.next_slot + 1) % kParamSlots;
@@ -283,6 +322,14 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         std::memcpy(sl->host, &kp, sizeof(kp));
         sl->used = true;
         HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, sizeof(kp), hipMemcpyHostToDevice, stream));
+        if (fe.on) {
+            // the n x n matrix goes from the front-end kernel straight into the block's grid_probs slot, on
+            // the launch stream, between the upload and the race kernel; the host copy is made unmatchable
+            sl->host->n = -1;
+            hipLaunchKernelGGL(grid_probs_kernel, dim3(1), dim3(mcgp::kMaxCars), 0, stream, c.d_fe_in, c.d_fe_pen,
+                               (int)kp.n, sl->dev->grid_probs);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(sl->uploaded, stream));
         sl->upload_stream = stream;
     } else if (sl->upload_stream != stream) {
@@ -428,6 +475,93 @@ int32_t mcgp_simulate_race(const mcgp_config *cfg, const mcgp_drivers *drv, cons
             if (e != hipSuccess) r = fail(MCGP_E_HIP, std::string("hipMemcpy(order): ") + hipGetErrorString(e));
         }
         return r;
+    };
+    rc = body();
+    delete kp;
+    return rc;
+}
+
+// Uploads the front-end inputs of one call into the context's buffers (NULL stream: ordered before what follows).
+static int upload_front_end(DeviceCtx &c, const double *rating, const double *teammate_delta, const double *form_score,
+                            const double *circuit_affinity, const int32_t *penalty, uint32_t n)
+{
+    if (!rating || !teammate_delta || !form_score || !circuit_affinity || !penalty)
+        return fail(MCGP_E_BAD_ARG, "a front-end input array is NULL");
+    if (n < 1 || n > MCGP_MAX_CARS) return fail(MCGP_E_BAD_ARG, "n must be in [1, 32]");
+    double in[4 * MCGP_MAX_CARS];
+    for (uint32_t d = 0; d < n; ++d) {
+        if (!(rating[d] == rating[d])) return fail(MCGP_E_BAD_ARG, "a quali rating is NaN");
+        in[d] = rating[d];
+        in[n + d] = teammate_delta[d];
+        in[2 * n + d] = form_score[d];
+        in[3 * n + d] = circuit_affinity[d];
+    }
+    HIP_TRY(hipMemcpy(c.d_fe_in, in, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.d_fe_pen, penalty, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    return MCGP_OK;
+}
+
+int32_t mcgp_grid_probs(const double *quali_rating, const double *teammate_delta, const double *form_score,
+                        const double *circuit_affinity, const int32_t *penalty, uint32_t n, int32_t device,
+                        double *grid_probs_out)
+{
+    if (!grid_probs_out) return fail(MCGP_E_BAD_ARG, "grid_probs_out is NULL");
+    DeviceCtx *c = nullptr;
+    int rc = find_ctx(device, &c);
+    if (rc != MCGP_OK) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto body = [&]() -> int {
+        int r = ensure_ctx_locked(device, *c);
+        if (r != MCGP_OK) return r;
+        HIP_TRY(hipSetDevice(device));
+        r = upload_front_end(*c, quali_rating, teammate_delta, form_score, circuit_affinity, penalty, n);
+        if (r != MCGP_OK) return r;
+        hipLaunchKernelGGL(grid_probs_kernel, dim3(1), dim3(mcgp::kMaxCars), 0, nullptr, c->d_fe_in, c->d_fe_pen, (int)n,
+                           c->d_fe_out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(grid_probs_out, c->d_fe_out, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        return MCGP_OK;
+    };
+    return body();
+}
+
+int32_t mcgp_run_from_ratings(const mcgp_config *cfg, const mcgp_drivers *drv, const double *quali_rating,
+                              const double *teammate_delta, const double *form_score,
+                              const double *circuit_affinity, const int32_t *penalty, uint32_t n, uint64_t n_sims,
+                              uint64_t sim_offset, uint64_t seed, int32_t device, uint64_t *hist_out,
+                              double *grid_probs_out)
+{
+    if (!hist_out) return fail(MCGP_E_BAD_ARG, "hist_out is NULL");
+    mcgp::KParams *kp = new (std::nothrow) mcgp::KParams;
+    if (!kp) return fail(MCGP_E_NOMEM, "host allocation failed");
+    int rc = build_params(cfg, drv, nullptr, n, kp);               // grid_probs slot left zero: the device fills it
+    DeviceCtx *c = nullptr;
+    if (rc == MCGP_OK) rc = find_ctx(device, &c);
+    if (rc != MCGP_OK) { delete kp; return rc; }
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto body = [&]() -> int {
+        int r = ensure_ctx_locked(device, *c);
+        if (r != MCGP_OK) return r;
+        HIP_TRY(hipSetDevice(device));
+        r = upload_front_end(*c, quali_rating, teammate_delta, form_score, circuit_affinity, penalty, n);
+        if (r != MCGP_OK) return r;
+        const size_t hist_bytes = sizeof(unsigned long long) * n * n;
+        HIP_TRY(hipMemsetAsync(c->d_hist, 0, hist_bytes, nullptr));
+        FrontEnd fe;
+        fe.on = true;
+        r = launch(*c, *kp, n_sims, sim_offset, seed, nullptr, c->d_hist, nullptr, nullptr, fe);
+        if (r != MCGP_OK) return r;
+        unsigned long long h[MCGP_MAX_CARS * MCGP_MAX_CARS];
+        HIP_TRY(hipMemcpy(h, c->d_hist, hist_bytes, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n * n; ++i) hist_out[i] += h[i];
+        if (grid_probs_out) {
+            // the matrix the race kernel sampled from: read back from the parameter block it was written into
+            hipLaunchKernelGGL(grid_probs_kernel, dim3(1), dim3(mcgp::kMaxCars), 0, nullptr, c->d_fe_in, c->d_fe_pen, (int)n,
+                               c->d_fe_out);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(grid_probs_out, c->d_fe_out, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        }
+        return MCGP_OK;
     };
     rc = body();
     delete kp;

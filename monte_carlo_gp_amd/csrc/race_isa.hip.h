@@ -273,6 +273,27 @@ __device__ __forceinline__ float4 lds_ld_float4(uint32_t addr)          // one d
     const v4f v = *reinterpret_cast<const MCGP_LDS v4f *>(addr);
     return make_float4(v.x, v.y, v.z, v.w);
 }
+struct f64x2 {
+    double x, y;
+};
+__device__ __forceinline__ f64x2 lds_ld_f64x2(uint32_t addr)             // one ds_read_b128 (16-byte aligned address)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = *reinterpret_cast<const MCGP_LDS v2d *>(addr);
+    return f64x2{v.x, v.y};
+}
+// {f64, u32, pad}: one ds_read_b128 (16-byte aligned address)
+__device__ __forceinline__ void lds_ld_f64_u32(uint32_t addr, double &d, uint32_t &u)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = *reinterpret_cast<const MCGP_LDS v4u *>(addr);
+    d = __hiloint2double((int)v.y, (int)v.x);
+    u = v.z;
+}
+// Keeps a value computed where it is written: the compiler may not sink its computation into one arm of a later
+// select and turn the select into a branch (no instruction is emitted).
+__device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
+
 // address of the dynamic LDS block as the hardware sees it
 __device__ __forceinline__ uint32_t lds_base_of(const void *p)
 {

@@ -353,6 +353,11 @@ __device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uin
     }
 }
 
+// Statistics hook of the host debugging build (tools/emu): nothing in the product build.
+#ifndef MCGP_STAT
+#define MCGP_STAT(what, value)
+#endif
+
 #ifndef MCGP_MIN_WAVES
 #define MCGP_MIN_WAVES 2
 #endif
@@ -454,7 +459,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 
     const double pit_loss = P->pit_loss;
     const double overtake_delta = P->overtake_delta;
-    const double drs_delta = P->drs_delta;
     const double dirty_thr = P->dirty_thr;
     const double dirty_pen = P->dirty_pen;
     const float kNaN = __uint_as_float(0x7fc00000u);
@@ -475,10 +479,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         r.last = lds_ld<double>(G::oLast + (r.a4 << 1));
         const uint32_t id16 = (p >> 6) & 0x1F0u;                                  // 16 x driver
         const uint32_t ic = id16 + ((p & k3CompMask) << 2);                       // 16 x (32 compound + driver)
-        r.var = lds_ld<double>(G::oDrvA + id16);
-        r.base = lds_ld<double>(G::oDrvA + 8 + id16);
-        r.eff = lds_ld<double>(G::oIc + ic);
-        r.opt = lds_ld<uint32_t>(G::oIc + 8 + ic);
+        const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);
+        r.var = vb.x;
+        r.base = vb.y;
+        lds_ld_f64_u32(G::oIc + ic, r.eff, r.opt);
         r.cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));                 // 16 x compound
         r.drs = lds_ld<double>(G::oDrs + (p & k3Drs));                            // 0.0 or drs_delta
         return r;
@@ -534,10 +538,22 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         lds_st<double>(l_row(d), acc);
                     }
                     const double cdf_last = acc;
+                    // searchsorted(cdf / cdf[-1], u, 'right'): the first driver with cdf[d] / cdf_last > u.  The
+                    // quotient is only formed when the answer is not already certain: fl(x / c) <= u for every
+                    // x <= fl(u c) (1 - 2^-50) and fl(x / c) > u for every x >= fl(u c) (1 + 2^-50) (the three
+                    // roundings involved move a value by at most 2^-52 relative), so the division -- a dozen
+                    // instructions on this hardware -- runs only for a cdf entry within 2^-49 of the threshold.
+                    const double uc = u * cdf_last;
+                    const double sure_le = uc * (1.0 - 0x1p-50), sure_gt = uc * (1.0 + 0x1p-50);
                     sel = (uint32_t)N;
                     for (uint32_t m = remaining; m; m &= m - 1u) {        // first driver whose cdf exceeds u
                         const int d = __ffs((int)m) - 1;
-                        if (sel == (uint32_t)N && !(lds_ld<double>(l_row(d)) / cdf_last <= u)) sel = (uint32_t)d;
+                        const double x = lds_ld<double>(l_row(d));
+                        bool exceeds;
+                        if (x <= sure_le) exceeds = false;
+                        else if (x >= sure_gt) exceeds = true;
+                        else exceeds = !(x / cdf_last <= u);
+                        if (sel == (uint32_t)N && exceeds) sel = (uint32_t)d;
                     }
                     if (sel >= (uint32_t)N) sel = 31u - (uint32_t)__clz((int)remaining);   // unreachable: cdf[-1] == 1 > u
                 }
@@ -621,38 +637,42 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const bool red = (uint64_t)e0 < t_red;
                 const bool sc = !red && (uint64_t)e1 < t_sc;
                 const bool vsc = !red && !sc && (uint64_t)e2 < t_vsc;
+                MCGP_STAT(12, red || sc || vsc);
                 if (!(MCGP_SKIP & 2) && (red || sc || vsc)) {
+                    // Only a few lanes of a wave are in here, but the wave pays for every instruction: the handlers
+                    // (:334-431) are one pass over the ranks without branches.  Running cars are re-spaced behind the
+                    // leader (red flag 0.1 s apart, safety car 0.5 s apart, VSC gaps x 0.8), their time_behind_leader
+                    // -- kept as the dirty-air flag -- follows, tyres age one lap less (SC; VSC with probability 0.3)
+                    // or are changed (red flag).  Retired cars are left alone.
                     const bool dec_age = sc || (vsc && (uint64_t)e3 < t_vsc_tire);
                     const uint32_t newc = stint_compound(track, remaining_laps);
-                    int k = 0;
-                    double leader = 0.0, prev_nt = -1.0;
-                    bool tie = false;
+                    const uint32_t red_bits = (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
+                    const uint32_t dec_unit = dec_age ? (1u << k3AgeShift) : 0u;
+                    const double step = red ? 0.1 : 0.5;
+                    double leader = 0.0, kd = 0.0, prev_nt = -1.0;
+                    bool first = true, tie = false;
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
-                        uint32_t p = pk[i];
-                        if (!(p & k3Dnf)) {
-                            const double t = cum[i];
-                            if (k == 0) leader = t;
-                            double nt;
-                            if (red) nt = leader + (double)k * 0.1;
-                            else if (sc) nt = leader + (double)k * 0.5;
-                            else { const double gap = t - leader; nt = leader + gap * 0.8; }
-                            tie |= nt == prev_nt;
-                            prev_nt = nt;
-                            const double tbl = nt - leader;
-                            p &= ~k3Dirty;
-                            if (tbl > 0 && tbl < dirty_thr) p |= k3Dirty;
-                            uint32_t age = (p >> k3AgeShift) & 0x7FFu;
-                            if (red) {
-                                age = 0u;
-                                p = (p & ~k3CompMask) | (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
-                            } else if (dec_age) {
-                                age = age > 0u ? age - 1u : 0u;
-                            }
-                            cum[i] = nt;
-                            pk[i] = (p & ~k3AgeMask) | (age << k3AgeShift);
-                            ++k;
-                        }
+                        const uint32_t p = pk[i];
+                        const bool act = !(p & k3Dnf);
+                        const double t = cum[i];
+                        leader = (act && first) ? t : leader;
+                        const double nt_fixed = leader + kd * step;                  // :363 / :412
+                        const double gap = t - leader;
+                        const double nt_vsc = leader + gap * 0.8;                    // :386-387
+                        const double nt = vsc ? nt_vsc : nt_fixed;
+                        tie |= act && nt == prev_nt;
+                        prev_nt = act ? nt : prev_nt;
+                        const double tbl = nt - leader;                             // :371 / :388 / :413
+                        uint32_t q = (p & ~k3Dirty) | ((tbl > 0 && tbl < dirty_thr) ? k3Dirty : 0u);
+                        const uint32_t agef = q & k3AgeMask;
+                        q -= agef < dec_unit ? agef : dec_unit;                     // max(0, tire_age - 1), :375 / :393-395
+                        const uint32_t q_red = (q & ~(k3CompMask | k3AgeMask)) | red_bits;   // :414-429
+                        q = red ? q_red : q;
+                        pk[i] = act ? q : p;
+                        cum[i] = act ? nt : t;
+                        kd = kd + (act ? 1.0 : 0.0);
+                        first = first && !act;
                     }
                     drs_disabled_until = lap + (vsc ? 1 : 2);
                     // Re-spacing keeps the running cars' relative order (the only order the lap loop below
@@ -740,8 +760,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const uint32_t u3 = (p & k3UsedMask) * 3u;
                         const uint32_t newc = (lut_comp >> u3) & 7u, newu = (lut_used >> u3) & 7u;
                         const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | (newc << k3CompShift) | newu;
-                        const uint32_t p_run = pit ? p_pit : p + (1u << k3AgeShift);
-                        const uint32_t p_ret = (p & ~k3AgeMask) | retire_bits;
+                        uint32_t p_run = pit ? p_pit : p + (1u << k3AgeShift);
+                        uint32_t p_ret = (p & ~k3AgeMask) | retire_bits;
+                        pin(p_run);              // both computed for every lane: the merge below stays a pair of selects
+                        pin(p_ret);
                         pk[i] = run ? p_run : retire ? p_ret : p;
                         // x + 0.0 == x for the finite, non-negative times here: cars that do not run keep their time
                         const double t = cum[i] + (run ? lap_time : 0.0);
@@ -771,8 +793,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         for (int j = 0; j < H; ++j) {
                             if (h + j < N) {
                                 const uint32_t id16 = (pk[h + j] >> 6) & 0x3F0u;      // 16 x (32 dnf + driver)
-                                pb[j] = lds_ld<double>(G::oDrvB + id16);
-                                pd[j] = lds_ld<double>(G::oDrvB + 8 + id16);
+                                const f64x2 bd = lds_ld_f64x2(G::oDrvB + id16);
+                                pb[j] = bd.x;
+                                pd[j] = bd.y;
                                 pa[j] = lds_ld<double>(G::oDrs + (pk[h + j] & k3Drs));
                             }
                         }
@@ -792,6 +815,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         }
                     }
                 }
+                MCGP_STAT(0 + pass, cand != 0u);
                 if (cand == 0u) break;
                 // ---- overtakes: draw words ----
                 // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4
@@ -828,6 +852,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     cum[i - 1] = hit ? na : cum[i - 1];
                     any_succ |= hit;
                 }
+                MCGP_STAT(4 + pass, any_succ);
+                MCGP_STAT(8, __popc(cand));
                 if (!any_succ) break;
                 // ---- overtakes: re-sort ----
                 resort_after_overtakes<N>(cum, pk);     // sorted again for the next pass / _update_positions
@@ -869,14 +895,28 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             lds_st<uint32_t>(z_row(j), pkx);
             lds_st<double>(l_row(j), kx);
         }
+        // finishing order: N bytes per simulation, contiguous per lane.  Four positions are packed into one dword
+        // store when the lane's N-byte record is dword aligned (N % 4 == 0 and an aligned buffer): N / 4 stores per
+        // lane that the L2 merges into full lines, instead of N single-byte stores.
+        const bool dword_orders = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(orders) & 3u) == 0);
+        uint32_t packed = 0u;
 #pragma unroll 1
         for (int p = 0; p < N; ++p) {
             const uint32_t d = (lds_ld<uint32_t>(z_row(p)) >> k3IdShift) & 31u;
             atomicAdd(&s_hist[d * N + p], 1u);                       // reference :93-94
-            if (orders) orders[local * (uint64_t)N + (uint64_t)p] = (uint8_t)d;
+            if (orders) {
+                if (dword_orders) {
+                    packed |= d << (8 * (p & 3));
+                    if ((p & 3) == 3) {
+                        *reinterpret_cast<uint32_t *>(orders + local * (uint64_t)N + (uint64_t)(p - 3)) = packed;
+                        packed = 0u;
+                    }
+                } else {
+                    orders[local * (uint64_t)N + (uint64_t)p] = (uint8_t)d;
+                }
+            }
         }
     }
-
 }
 
 template <int N>

@@ -125,9 +125,12 @@ def actual_grid_probs(drivers, actual_grid: dict) -> dict:
 class F1Predictor:
     """predict_weekend over a race fixture; the Monte Carlo step runs on the GPU."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, device_front_end: bool = False):
+        """device_front_end: build the grid-probability matrix on the GPU next to the race kernel
+        instead of on the host; the matrices agree to ~1e-15 (the device uses its own exp, csrc/frontend_exp.h)."""
         self.elo_system = F1EloSystem()
         self.device = device
+        self.device_front_end = device_front_end
 
     def simulator_inputs(self, fixture: dict, race: str, grid_penalties=None, circuit=None,
                          prediction_point: str = 'fp2', actual_grid=None):
@@ -177,6 +180,14 @@ class F1Predictor:
             raise ValueError(f"No practice data available for {season} {race}")       # :183-184
         inp = self.simulator_inputs(fixture, race, grid_penalties, circuit_info, prediction_point, actual_grid)
         sim = RaceSimulator(inp['config'], device=self.device)
+        if self.device_front_end and not (actual_grid and prediction_point in ('quali', 'sprint')):
+            # same inputs, the matrix built on the device from the ratings (no host matrix crosses PCIe)
+            ratings = {d: self.elo_system.ratings.get(d, {}).get('quali', self.elo_system.initial) for d in inp['drivers']}
+            race_probs, grid = sim.run_from_ratings(
+                n_simulations, inp['drivers'], ratings, fixture.get('quali_features', {}), grid_penalties or {},
+                inp['base_pace'], inp['tire_deg'], inp['driver_variance'], inp['driver_dnf_rates'], seed=seed,
+                track_condition=inp['track_condition'])
+            return pack_result(inp['drivers'], grid, race_probs, inp['weather'], prediction_point, actual_grid)
         race_probs = sim.run_monte_carlo(
             n_simulations=n_simulations, grid_probs=inp['grid_probs'], base_pace=inp['base_pace'],
             tire_deg=inp['tire_deg'], driver_variance=inp['driver_variance'],

@@ -230,6 +230,48 @@ class RaceSimulator:
             self._resolve_seed(seed), self.device, order.ctypes.data_as(C.POINTER(C.c_uint8))))
         return [(drivers[int(d)], p + 1) for p, d in enumerate(order)]
 
+    # ------------------------------------------------------------------ device grid-probability front end
+    @staticmethod
+    def front_end_arrays(drivers, quali_ratings, quali_features=None, penalties=None, initial_rating=1500.0):
+        """Dense inputs of the device front end with the reference's .get() defaults resolved
+        (src/elo.py:131 initial rating; src/predictor.py:335,352-354 features default 0; :386-390 penalties)."""
+        from .predictor import _penalty_value
+        quali_features, penalties = quali_features or {}, penalties or {}
+        f = lambda key: np.array([quali_features.get(d, {}).get(key, 0) for d in drivers], np.float64)
+        rating = np.array([quali_ratings.get(d, initial_rating) for d in drivers], np.float64)
+        pen = np.array([int(_penalty_value(penalties.get(d, 0))) for d in drivers], np.int32)
+        return rating, f('teammate_delta'), f('form_score'), f('circuit_affinity'), pen
+
+    def grid_probs_on_device(self, drivers, quali_ratings, quali_features=None, penalties=None):
+        """{driver: [P(grid slot)]} computed by the device front end (include/mcgp.h: mcgp_grid_probs)."""
+        drivers = [str(d) for d in drivers]
+        n = len(drivers)
+        r, td, fs, ca, pen = self.front_end_arrays(drivers, quali_ratings, quali_features, penalties)
+        out = np.zeros((n, n), np.float64)
+        N.check(N.lib().mcgp_grid_probs(_dptr(r), _dptr(td), _dptr(fs), _dptr(ca),
+                                        pen.ctypes.data_as(C.POINTER(C.c_int32)), n, self.device, _dptr(out)))
+        return {d: [float(x) for x in out[i]] for i, d in enumerate(drivers)}
+
+    def run_from_ratings(self, n_simulations, drivers, quali_ratings, quali_features, penalties, base_pace, tire_deg,
+                         driver_variance, driver_dnf_rates=None, seed=None, track_condition='dry', sim_offset=0):
+        """run_monte_carlo with the grid matrix built ON THE DEVICE from the Elo quali ratings and features and
+        handed to the race kernel without a host round trip (mcgp_run_from_ratings).
+        Returns (position probabilities as run_monte_carlo does, {driver: [P(grid slot)]})."""
+        drivers = [str(d) for d in drivers]
+        prob = self._problem(drivers, base_pace, tire_deg, driver_variance, driver_dnf_rates, track_condition)
+        n = prob.n
+        r, td, fs, ca, pen = self.front_end_arrays(drivers, quali_ratings, quali_features, penalties)
+        hist = np.zeros((n, n), np.uint64)
+        grid = np.zeros((n, n), np.float64)
+        N.check(N.lib().mcgp_run_from_ratings(
+            C.byref(prob.cfg), C.byref(prob.drv), _dptr(r), _dptr(td), _dptr(fs), _dptr(ca),
+            pen.ctypes.data_as(C.POINTER(C.c_int32)), n, int(n_simulations), int(sim_offset), self._resolve_seed(seed),
+            self.device, hist.ctypes.data_as(C.POINTER(C.c_uint64)), _dptr(grid)))
+        self.last_histogram = hist.astype(np.int64)
+        self.last_drivers = drivers
+        return (histogram_to_probs(self.last_histogram, drivers, n_simulations),
+                {d: [float(x) for x in grid[i]] for i, d in enumerate(drivers)})
+
     # ------------------------------------------------------------------ north-star alias
     def set_race_inputs(self, base_pace=None, tire_deg=None, driver_variance=None, driver_dnf_rates=None,
                         track_condition='dry'):

@@ -743,3 +743,21 @@ int orc_sample_grid_mt(const double *grid_probs, int32_t n, orc_mt_state *mt, ui
     sample_grid(grid_probs, n, &r, grid_out);
     return 0;
 }
+
+/* ---- grid-probability front end (reference src/elo.py:124-141, src/predictor.py:321-407) ----
+ * CPU side of the checker for the device front end: the same header text as the HIP kernel compiles. */
+#include "frontend_exp.h"
+
+double orc_fe_exp(double x) { return mcgp_fe_exp(x); }
+
+int orc_grid_probs(const double *rating, const double *teammate_delta, const double *form_score,
+                   const double *circuit_affinity, const int32_t *penalty, int32_t n, double *out)
+{
+    if (!rating || !teammate_delta || !form_score || !circuit_affinity || !penalty || !out) return -1;
+    if (n < 1 || n > MCGP_ORACLE_MAX_CARS) return -1;
+    double p[MCGP_ORACLE_MAX_CARS], tmp[MCGP_ORACLE_MAX_CARS];
+    mcgp_fe_pole_probs(rating, teammate_delta, n, p);
+    for (int d = 0; d < n; d++)
+        mcgp_fe_grid_row(p[d], form_score[d], circuit_affinity[d], penalty[d], n, out + (size_t)d * n, tmp);
+    return 0;
+}

@@ -109,6 +109,12 @@ int orc_simulate_race(const orc_config *cfg, const orc_drivers *drv, const uint8
 /* _sample_grid only (reference :102-145), MT back-end; for the G5 fixtures. */
 int orc_sample_grid_mt(const double *grid_probs, int32_t n, orc_mt_state *mt, uint8_t *grid_out);
 
+/* Grid-probability front end, reference src/elo.py:124-141 + src/predictor.py:321-407, with the front end's own
+ * exp (frontend_exp.h).  out: n x n row-major [driver][grid slot]. */
+double orc_fe_exp(double x);
+int orc_grid_probs(const double *rating, const double *teammate_delta, const double *form_score,
+                   const double *circuit_affinity, const int32_t *penalty, int32_t n, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ run)
   : > $out
   for rep in 1 2; do
     for v in $VARIANTS; do
-      ms=$(MCGP_LIB=$PWD/abl/libmcgp_${v//=/_}.so MCGP_BENCH_NOCHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline \
+      ms=$(MCGP_LIB=$PWD/abl/libmcgp_${v//=/_}.so MCGP_BENCH_NOCHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras \
            --sims-per-step ${SIMS:-4000000} 2>/dev/null | python -c "import json,sys; print(json.load(sys.stdin)['roofline']['kernel_ms_avg'])")
       echo "$v kernel_ms=$ms" | tee -a $out
     done

@@ -4,6 +4,11 @@
 // flush) for the threads of one block one after another, so a kernel edit can be compared with the oracle on
 // the CPU before a GPU run.  tests/test_kernel_host_build.py.
 //   g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -Itools/emu -o tools/emu/libmcgp_emu.so tools/emu/emu_kernel.cpp
+#include <cstdint>
+// statistics hook: counts[what] += value, calls[what] += 1
+extern "C" unsigned long long emu_stat_sum[16], emu_stat_calls[16];
+unsigned long long emu_stat_sum[16], emu_stat_calls[16];
+#define MCGP_STAT(what, value) (emu_stat_sum[(what)] += (unsigned long long)(value), emu_stat_calls[(what)] += 1)
 #include "race_isa_host.h"
 
 #include "../../monte_carlo_gp_amd/csrc/params_build.h"

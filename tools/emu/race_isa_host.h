@@ -71,6 +71,16 @@ inline void lds_st(uint32_t addr, T v)
 {
     std::memcpy(smem + addr, &v, sizeof(T));
 }
+struct f64x2 {
+    double x, y;
+};
+inline f64x2 lds_ld_f64x2(uint32_t addr) { return lds_ld<f64x2>(addr); }
+inline void lds_ld_f64_u32(uint32_t addr, double &d, uint32_t &u)
+{
+    d = lds_ld<double>(addr);
+    u = lds_ld<uint32_t>(addr + 8);
+}
+inline void pin(uint32_t &) {}
 inline float4 lds_ld_float4(uint32_t addr) { return lds_ld<float4>(addr); }
 inline uint32_t lds_base_of(const void *p) { return (uint32_t)((const unsigned char *)p - smem); }
 }  // namespace mcgp
