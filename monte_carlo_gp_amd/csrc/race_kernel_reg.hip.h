@@ -42,6 +42,11 @@
 
 #include <utility>
 
+// Statistics hook of the host debugging build (tools/emu): nothing in the product build.
+#ifndef MCGP_STAT
+#define MCGP_STAT(what, value)
+#endif
+
 namespace mcgp {
 
 // pk word of the register kernel.  Field positions are chosen so that LDS addresses fall out of one
@@ -282,7 +287,9 @@ __device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N]
 {
     constexpr MergeExchange<N> net{};
     network_sort_impl<N>(cum, pk, std::make_index_sequence<(size_t)net.n_groups>{});
-    if (__builtin_expect(!strictly_increasing<N>(cum), 0)) {
+    const bool strict = strictly_increasing<N>(cum);
+    MCGP_STAT(13, !strict);
+    if (__builtin_expect(!strict, 0)) {
         if (!ties_in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
     }
 }
@@ -298,32 +305,35 @@ __device__ __forceinline__ void resort_after_overtakes(double (&cum)[N], uint32_
 {
     bubble_forward<N, 0>(cum, pk);                 // (0,1), (1,2), .. (N-2,N-1)
     bubble_backward<N, N - 2>(cum, pk);            // (N-3,N-2), .. (0,1): the last slot already holds the maximum
-    if (__builtin_expect(!strictly_increasing<N>(cum), 0)) {
+    const bool strict = strictly_increasing<N>(cum);
+    MCGP_STAT(14, !strict);
+    if (__builtin_expect(!strict, 0)) {
         if (!in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
     }
 }
 
-// _update_positions, reference :538-560.
+// _update_positions, reference :538-560: gap to the leader (kept as the dirty-air flag, :209-212) and the DRS flag
+// of every running car, in rank order; retired cars are skipped.
 template <int N>
 __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uint32_t (&pk)[N],
                                                      bool drs_allowed, double dirty_thr)
 {
     bool first = true;
     double leader = 0.0, prev = 0.0;
+    // one straight pass, merged by selects (a few lanes hold retired cars; the wave would pay for the branches)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        uint32_t p = pk[i];
-        if (!(p & k3Dnf)) {
-            const double t = cum[i];
-            if (first) leader = t;
-            const double tbl = t - leader;
-            p &= ~(k3Drs | k3Dirty);
-            if (tbl > 0 && tbl < dirty_thr) p |= k3Dirty;
-            if (!first && drs_allowed && (t - prev) < 1.0) p |= k3Drs;
-            pk[i] = p;
-            prev = t;
-            first = false;
-        }
+        const uint32_t p = pk[i];
+        const bool act = !(p & k3Dnf);
+        const double t = cum[i];
+        leader = (act && first) ? t : leader;
+        const double tbl = t - leader;                                               // :551
+        const bool dirty = tbl > 0 && tbl < dirty_thr;
+        const bool drs = !first && drs_allowed && (t - prev) < 1.0;                  // :553-558
+        const uint32_t q = (p & ~(k3Drs | k3Dirty)) | (dirty ? k3Dirty : 0u) | (drs ? k3Drs : 0u);
+        pk[i] = act ? q : p;
+        prev = act ? t : prev;
+        first = first && !act;
     }
 }
 
@@ -352,11 +362,6 @@ __device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uin
         lut_used |= ((used | (1u << newc)) & 7u) << (3 * used);
     }
 }
-
-// Statistics hook of the host debugging build (tools/emu): nothing in the product build.
-#ifndef MCGP_STAT
-#define MCGP_STAT(what, value)
-#endif
 
 #ifndef MCGP_MIN_WAVES
 #define MCGP_MIN_WAVES 2

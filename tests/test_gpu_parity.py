@@ -191,7 +191,13 @@ def test_cached_parameter_block_across_streams(require_gpu):
     from monte_carlo_gp_amd import _native as N
     from monte_carlo_gp_amd.simulation import _Problem, _dptr, RaceSimulator
     from monte_carlo_gp_amd import RaceConfig
-    hip = C.CDLL('/opt/rocm/lib/libamdhip64.so')
+    N.lib()
+    # the HIP runtime this process already has mapped (the one libmcgp_hip.so resolved against; a process that
+    # imported torch first carries torch's bundled copy): never load a second one
+    with open('/proc/self/maps') as f:
+        paths = sorted({line.split()[-1] for line in f if 'libamdhip64' in line})
+    assert paths, 'libmcgp_hip.so is loaded but no libamdhip64 is mapped?'
+    hip = C.CDLL(paths[0])
 
     def ok(rc):
         assert rc == 0, f'HIP error {rc}'

@@ -43,3 +43,24 @@ def test_offsets_and_64bit_seeds():
     ref = O.Problem(case).run(400, rng=O.RNG_PHILOX, seed=seed, sim_offset=base, want_orders=True)
     hist, orders = K.run(case, 400, seed, sim_offset=base)
     assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+
+
+def test_inverse_normal_transform_matches_the_oracle_word_for_word():
+    """race_common.hip.h: normal_from_u32 against the oracle's, on the cells parity runs never reach (the 16
+    smallest tail cells of either sign have probability 7e-9 per draw), every segment boundary, and a random sample."""
+    import ctypes as C
+    L = K.lib()
+    L.emu_normal_from_u32.restype = C.c_float
+    L.emu_normal_from_u32.argtypes = [C.c_uint32]
+    Lo = O.lib()
+    Lo.orc_normal_from_u32.restype = C.c_float
+    Lo.orc_normal_from_u32.argtypes = [C.c_uint32]
+    rng = np.random.default_rng(3)
+    words = list(range(0, 64)) + [0x80000000 | i for i in range(64)]
+    for b in range(4, 32):
+        for d in (-2, -1, 0, 1, 2):
+            words += [((1 << b) + d) & 0xffffffff, ((1 << b) + d + (1 << (b - 1))) & 0xffffffff]
+    words += [0x7fffffff, 0xffffffff, 0x7ffffff0, 0xfffffff0] + [int(x) for x in rng.integers(0, 2 ** 32, 20000)]
+    for w in words:
+        a, b = L.emu_normal_from_u32(w), Lo.orc_normal_from_u32(w)
+        assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), hex(w)

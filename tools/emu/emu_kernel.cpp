@@ -21,6 +21,12 @@ namespace mcgp {
 alignas(16) unsigned char smem[1 << 20];
 }
 
+// the kernel's inverse-normal transform (race_common.hip.h) on the host, for the known-answer test of its tail cells
+extern "C" float emu_normal_from_u32(uint32_t w)
+{
+    return mcgp::normal_from_u32(w, reinterpret_cast<const float4 *>(mcgp_normal_table_bits));
+}
+
 #define EMU_SIZES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) \
     X(19) X(20) X(21) X(22) X(23) X(24)
 
