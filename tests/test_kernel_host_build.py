@@ -28,7 +28,7 @@ def test_fuzzed_configurations():
     with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
         cases = json.load(f)
     for name, c in cases.items():
-        if not (2 <= len(c['grid_probs']) <= 24):
+        if not (2 <= len(c["grid_probs"]) <= 32):
             continue                                   # field sizes served by the generic LDS kernel
         ref = O.Problem(c).run(300, rng=O.RNG_PHILOX, seed=c['seed'], want_orders=True)
         hist, orders = K.run(c, 300, c['seed'])
@@ -64,3 +64,25 @@ def test_inverse_normal_transform_matches_the_oracle_word_for_word():
     for w in words:
         a, b = L.emu_normal_from_u32(w), Lo.orc_normal_from_u32(w)
         assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), hex(w)
+
+
+@pytest.mark.parametrize('n', [2, 5, 13, 25, 28, 32])
+def test_field_sizes_up_to_the_abi_maximum(n):
+    """Every register instantiation is the same source; sizes beyond the golden / fuzz cases, with an all-zero
+    grid column (uniform fallback, reference :126-129) and per-driver spreads."""
+    rng = np.random.default_rng(n)
+    drivers = [f'D{i:02d}' for i in range(n)]
+    base = O.load_case('S60')
+    case = dict(base)
+    case['config'] = dict(base['config'], total_laps=30,
+                          driver_teams={d: list(base['config']['dnf_rates'])[i % 10] for i, d in enumerate(drivers)})
+    g = rng.random((n, n))
+    g[:, n // 2] = 0.0
+    case['grid_probs'] = {d: [float(x) for x in g[i]] for i, d in enumerate(drivers)}
+    case['base_pace'] = {d: 90.0 + 0.15 * i for i, d in enumerate(drivers)}
+    case['tire_deg'] = {d: 0.03 + 0.002 * i for i, d in enumerate(drivers)}
+    case['driver_variance'] = {d: 0.2 for d in drivers}
+    case['driver_dnf_rates'] = {d: 0.01 for d in drivers}
+    ref = O.Problem(case).run(300, rng=O.RNG_PHILOX, seed=5, want_orders=True)
+    hist, orders = K.run(case, 300, 5)
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])

@@ -72,7 +72,7 @@ def test_elo_updates_match_reference(misc):
     e.update_race_ratings([(d, ((i * 3) % 20) + 1) for i, d in enumerate(drivers)])
     for d in drivers:
         for k in ('quali', 'race'):
-            assert e.ratings[d][k] == pytest.approx(misc['elo_after'][d][k], rel=0, abs=1e-9)
+            assert e.ratings[d][k] == misc['elo_after'][d][k]          # bit-identical (same operations, same order)
 
 
 @pytest.mark.parametrize('label', ['dry_fp2', 'damp_quali'])

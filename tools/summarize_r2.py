@@ -16,6 +16,7 @@ VALUBusy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), the gfx
 """
 import collections
 import csv
+import re
 import glob
 import json
 import os
@@ -117,6 +118,9 @@ def main():
         k = w.get('kernel', {})
         base = name.split('_')[0]
         L = laps.get(base, 60)
+        m = re.search(r'(\d+) laps', w.get('bench_under_rocprof', {}).get('workload', ''))
+        if m:
+            L = int(m.group(1))
         waves = w['sims_per_launch'] / 64
         ms = w.get('kernel_ms_avg_stats')
         per = lambda key: f"{w[key] / waves / L:.0f}" if key in w else '?'
