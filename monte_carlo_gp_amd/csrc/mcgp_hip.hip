@@ -44,6 +44,8 @@ int fail(int code, const std::string &msg)
 // Field sizes with a register-resident instantiation; every other n runs the generic LDS kernel.
 #ifdef MCGP_ONLY_N20      // diagnostic builds (tools/ablate.sh)
 #define MCGP_REG_SIZES(X) X(20)
+#elif defined(MCGP_ONLY_N)
+#define MCGP_REG_SIZES(X) X(MCGP_ONLY_N)
 #else
 #define MCGP_REG_SIZES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) \
     X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
@@ -84,6 +86,7 @@ struct DeviceCtx {
         hipEvent_t uploaded = nullptr;        // recorded after the upload of `dev`; other streams wait on it
         hipStream_t upload_stream = nullptr;
         bool used = false;
+        bool shareable = false;               // false: the device copy differs from `host` (matrix written by the front end)
     } slot[kParamSlots];
     int next_slot = 0;
     unsigned long long *d_hist = nullptr;     // scratch for the host-buffer entry points
@@ -314,18 +317,19 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     DeviceCtx::Slot *sl = nullptr;
     if (!fe.on)           // a block whose matrix is written by the device front end is never shared
         for (auto &cand : c.slot)
-            if (cand.used && std::memcmp(cand.host, &kp, sizeof(kp)) == 0) { sl = &cand; break; }
+            if (cand.used && cand.shareable && std::memcmp(cand.host, &kp, sizeof(kp)) == 0) { sl = &cand; break; }
     if (!sl) {
         sl = &c.slot[c.next_slot];
         c.next_slot = (c.next_slot + 1) % kParamSlots;
         if (sl->used) HIP_TRY(hipEventSynchronize(sl->done));   // its last reader has finished
         std::memcpy(sl->host, &kp, sizeof(kp));
         sl->used = true;
+        sl->shareable = !fe.on;
         HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, sizeof(kp), hipMemcpyHostToDevice, stream));
         if (fe.on) {
             // the n x n matrix goes from the front-end kernel straight into the block's grid_probs slot, on
-            // the launch stream, between the upload and the race kernel; the host copy is made unmatchable
-            sl->host->n = -1;
+            // the launch stream, between the upload and the race kernel (the slot is marked not shareable:
+            // its pinned host copy, still being read by the asynchronous upload, no longer describes it)
             hipLaunchKernelGGL(grid_probs_kernel, dim3(1), dim3(mcgp::kMaxCars), 0, stream, c.d_fe_in, c.d_fe_pen,
                                (int)kp.n, sl->dev->grid_probs);
             HIP_TRY(hipGetLastError());

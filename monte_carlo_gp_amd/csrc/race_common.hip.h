@@ -79,14 +79,16 @@ template <typename RowFn>
 __device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
 {
     const uint32_t m = w & 0x7fffffffu;
-    const uint32_t mm = m < 16u ? 16u : m;              // max(m, 16): the 16 smallest tail cells have rows of their own
+    const bool small = m < 16u;
+    const uint32_t mm = small ? 16u : m;
     const int sh = 27 - __clz((int)mm);                 // floor(log2 mm) - 4
     const uint32_t k = (mm >> sh) & 15u;
     const uint32_t r = mm & ((1u << sh) - 1u);
-    // t of the generator is 0 for m < 16; those rows are constants (c1 = c2 = c3 = +0), so the value computed
-    // from mm = 16 (t = 0.5) gives the same bits and the select is not needed
-    const float t = ((float)r + 0.5f) * __uint_as_float((uint32_t)(127 - sh) << 23);
-    const uint32_t row = m < 16u ? m : 16u + 16u * (uint32_t)sh + k;
+    float t = ((float)r + 0.5f) * __uint_as_float((uint32_t)(127 - sh) << 23);
+    t = small ? 0.0f : t;                               // (the 16 tail rows are constants; measured: this form, which
+                                                        //  hipcc compiles to a never-skipped branch, is 0.8 % faster
+                                                        //  than the select-free one)
+    const uint32_t row = small ? m : 16u + 16u * (uint32_t)sh + k;
     const float4 c = row_of(row);
     float z = __builtin_fmaf(c.w, t, c.z);
     z = __builtin_fmaf(z, t, c.y);

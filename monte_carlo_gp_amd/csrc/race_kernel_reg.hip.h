@@ -931,8 +931,9 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
                 uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // host and kernel must agree on the geometry; the rows are addressed by absolute LDS address (race_isa.hip.h)
-    if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) return;
+    // host and kernel must agree on the geometry, and the rows are addressed by absolute LDS address
+    // (race_isa.hip.h): a violation aborts the launch (a HIP error at the next synchronisation), never a silent result
+    if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) __builtin_trap();
     reg_load_tables<N>(P, smem, threadIdx.x);
     __syncthreads();
     reg_simulate<N>(P, smem, threadIdx.x, blockIdx.x, gridDim.x, n_sims, sim_offset, seed_lo, seed_hi, orders,

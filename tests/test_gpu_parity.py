@@ -233,3 +233,42 @@ def test_cached_parameter_block_across_streams(require_gpu):
             assert np.array_equal(h.astype(np.int64), ref), name
     for st in streams[:2]:
         ok(hip.hipStreamDestroy(st))
+
+
+def test_orders_into_an_unaligned_device_buffer(require_gpu):
+    """mcgp_run_device with d_orders one byte off dword alignment: the kernel falls back from packed dword stores
+    to byte stores (n = 20 and n = 24 are the sizes that otherwise take the packed path)."""
+    import ctypes as C
+    from monte_carlo_gp_amd import _native as N
+    from monte_carlo_gp_amd.simulation import _Problem, _dptr, RaceSimulator
+    from monte_carlo_gp_amd import RaceConfig
+    N.lib()
+    with open('/proc/self/maps') as f:
+        paths = sorted({line.split()[-1] for line in f if 'libamdhip64' in line})
+    hip = C.CDLL(paths[0])
+
+    def ok(rc):
+        assert rc == 0, f'HIP error {rc}'
+    ok(hip.hipSetDevice(0))
+    case = O.load_case('S60')
+    drivers = list(case['grid_probs'])
+    p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
+                 case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
+    g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+    n_sims = 1000
+    ref = O.Problem(case).run(n_sims, rng=O.RNG_PHILOX, seed=4, want_orders=True)
+    d_hist, d_orders = C.c_void_p(), C.c_void_p()
+    ok(hip.hipMalloc(C.byref(d_hist), C.c_size_t(p.n * p.n * 8)))
+    ok(hip.hipMalloc(C.byref(d_orders), C.c_size_t(n_sims * p.n + 16)))
+    for shift in (0, 1, 2, 3):
+        ok(hip.hipMemset(d_hist, 0, C.c_size_t(p.n * p.n * 8)))
+        ok(hip.hipMemset(d_orders, 0xEE, C.c_size_t(n_sims * p.n + 16)))
+        N.check(N.lib().mcgp_run_device(C.byref(p.cfg), C.byref(p.drv), _dptr(g), p.n, n_sims, 0, 4, 0, C.c_void_p(0),
+                                        d_hist, C.c_void_p(d_orders.value + shift)))
+        ok(hip.hipDeviceSynchronize())
+        raw = np.zeros(n_sims * p.n + 16, np.uint8)
+        ok(hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), d_orders, C.c_size_t(raw.size), 2))
+        assert np.array_equal(raw[shift:shift + n_sims * p.n].reshape(n_sims, p.n), ref['orders']), shift
+        assert (raw[:shift] == 0xEE).all() and (raw[shift + n_sims * p.n:] == 0xEE).all(), shift     # nothing written outside
+    ok(hip.hipFree(d_hist))
+    ok(hip.hipFree(d_orders))
