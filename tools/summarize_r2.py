@@ -29,9 +29,16 @@ PASSES = ('sq1', 'sq2', 'grbm', 'fetch', 'write')
 SIMS = 10_000_000
 
 
+def newest(paths):
+    """gpurun merges each call's files INTO gpurun_out/: a pass directory may still hold an earlier call's file
+    (other PID in the name).  Keep the newest one."""
+    paths = sorted(paths, key=os.path.getmtime)
+    return paths[-1:]
+
+
 def counters(tag, name, sub):
     acc, meta = collections.defaultdict(list), {}
-    for f in glob.glob(os.path.join(ROOT, 'gpurun_out', f'{tag}_{name}_{sub}', '*', '*_counter_collection.csv')):
+    for f in newest(glob.glob(os.path.join(ROOT, 'gpurun_out', f'{tag}_{name}_{sub}', '*', '*_counter_collection.csv'))):
         for r in csv.DictReader(open(f)):
             if 'race_kernel' in r['Kernel_Name']:
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
@@ -48,7 +55,7 @@ def one(tag, name):
         meta = m or meta
     if not c:
         return None
-    stats = glob.glob(os.path.join(ROOT, 'gpurun_out', f'{tag}_{name}_stats', '*', '*_kernel_stats.csv'))
+    stats = newest(glob.glob(os.path.join(ROOT, 'gpurun_out', f'{tag}_{name}_stats', '*', '*_kernel_stats.csv')))
     kernel_ms = calls = None
     if stats:
         shutil.copy(stats[0], os.path.join(OUT, f'{tag}_{name}_kernel_stats.csv'))
