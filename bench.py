@@ -296,7 +296,8 @@ def main():
             valu = {'bound': 'valu-issue', 'achieved': insts / (kavg_ms * 1e-3) / 1e12, 'peak': VALU_PEAK_TINST,
                     'unit': 'T wave-instructions/s', 'frac': insts / (kavg_ms * 1e-3) / 1e12 / VALU_PEAK_TINST,
                     'valu_insts_per_launch': insts, 'active_lane_ratio': pc.get('active_lane_ratio'),
-                    'valu_busy_profiled': pc.get('valu_busy'), 'source_hash': pc.get('source_hash_checked')}
+                    'valu_busy_profiled': pc.get('valu_busy'), 'source_hash': pc.get('source_hash'),
+                    'counters': 'profiles/r2_counters.json (rocprofv3 --pmc, tools/profile_r2.sh), same source hash as the loaded library'}
         out = {
             'metric': f'race-simulations/sec ({n} drivers, {L} laps)',
             'value': r['total'] / r['elapsed'],

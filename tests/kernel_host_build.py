@@ -19,8 +19,15 @@ def build():
     srcs = [os.path.join(EMU_DIR, f) for f in ('emu_kernel.cpp', 'race_isa_host.h', 'hip/hip_runtime.h')]
     srcs += [os.path.join(CSRC, f) for f in ('race_kernel_reg.hip.h', 'race_common.hip.h', 'params_build.h', 'normal_table.h')]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared',
-                               '-I' + EMU_DIR, '-o', LIB, os.path.join(EMU_DIR, 'emu_kernel.cpp')])
+        # four translation units (field sizes n % 4 == k) compiled side by side, then linked
+        flags = ['-O1', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-I' + EMU_DIR, '-DEMU_PARTS=4']
+        objs = [os.path.join(EMU_DIR, f'emu_part{k}.o') for k in range(4)]
+        procs = [subprocess.Popen(['g++'] + flags + [f'-DEMU_PART={k}', '-c', '-o', objs[k],
+                                                     os.path.join(EMU_DIR, 'emu_kernel.cpp')]) for k in range(4)]
+        for pr in procs:
+            if pr.wait() != 0:
+                raise RuntimeError('host build of the kernel sources failed')
+        subprocess.check_call(['g++', '-shared', '-o', LIB] + objs)
     return LIB
 
 

@@ -7,7 +7,9 @@
 #include <cstdint>
 // statistics hook: counts[what] += value, calls[what] += 1
 extern "C" unsigned long long emu_stat_sum[16], emu_stat_calls[16];
+#if !defined(EMU_PART) || EMU_PART == 0
 unsigned long long emu_stat_sum[16], emu_stat_calls[16];
+#endif
 #define MCGP_STAT(what, value) (emu_stat_sum[(what)] += (unsigned long long)(value), emu_stat_calls[(what)] += 1)
 #include "race_isa_host.h"
 
@@ -16,19 +18,68 @@ unsigned long long emu_stat_sum[16], emu_stat_calls[16];
 
 #include <vector>
 
+#if !defined(EMU_PART) || EMU_PART == 0
 emu_dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
 namespace mcgp {
 alignas(16) unsigned char smem[1 << 20];
 }
+#endif
 
+#if !defined(EMU_PART) || EMU_PART == 0
 // the kernel's inverse-normal transform (race_common.hip.h) on the host, for the known-answer test of its tail cells
 extern "C" float emu_normal_from_u32(uint32_t w)
 {
     return mcgp::normal_from_u32(w, reinterpret_cast<const float4 *>(mcgp_normal_table_bits));
 }
+#endif
 
-#define EMU_SIZES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) \
+// The field sizes are spread over EMU_PARTS translation units (compiled in parallel by tests/kernel_host_build.py):
+// unit EMU_PART holds the sizes n with n % EMU_PARTS == EMU_PART and exports emu_run_part<EMU_PART>; unit 0 also
+// holds the dispatcher emu_run.
+#ifndef EMU_PARTS
+#define EMU_PARTS 1
+#define EMU_PART 0
+#endif
+#define EMU_ALL_SIZES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) \
     X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+
+template <int N>
+static int run_size(const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offset, uint64_t seed, unsigned long long *hist,
+                    uint8_t *orders, const uint8_t *fixed_grid)
+{
+    if constexpr (N % EMU_PARTS == EMU_PART) {
+        // one block at a time; inside a block the three phases of the kernel run for every "thread" in turn
+        constexpr uint32_t B = mcgp::RegGeo<N>::B;
+        const uint32_t n_batches = (uint32_t)((n_sims + B - 1) / B);
+        for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N>(&kp, mcgp::smem, t);
+        for (uint32_t t = 0; t < B; ++t)
+            mcgp::reg_simulate<N>(&kp, mcgp::smem, t, 0u, 1u, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32),
+                                  orders, fixed_grid, n_batches);
+        for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N>(mcgp::smem, t, hist);
+        return 0;
+    } else {
+        return -2;
+    }
+}
+
+#define EMU_CAT2(a, b) a##b
+#define EMU_CAT(a, b) EMU_CAT2(a, b)
+extern "C" int EMU_CAT(emu_run_part, EMU_PART)(const mcgp::KParams *kp, uint32_t n, uint64_t n_sims, uint64_t sim_offset,
+                                               uint64_t seed, unsigned long long *hist, uint8_t *orders,
+                                               const uint8_t *fixed_grid)
+{
+    switch (n) {
+#define X(N_) case N_: return run_size<N_>(*kp, n_sims, sim_offset, seed, hist, orders, fixed_grid);
+        EMU_ALL_SIZES(X)
+#undef X
+        default: return -1;
+    }
+}
+
+#if EMU_PART == 0
+extern "C" int emu_run_part1(const mcgp::KParams *, uint32_t, uint64_t, uint64_t, uint64_t, unsigned long long *, uint8_t *, const uint8_t *);
+extern "C" int emu_run_part2(const mcgp::KParams *, uint32_t, uint64_t, uint64_t, uint64_t, unsigned long long *, uint8_t *, const uint8_t *);
+extern "C" int emu_run_part3(const mcgp::KParams *, uint32_t, uint64_t, uint64_t, uint64_t, unsigned long long *, uint8_t *, const uint8_t *);
 
 extern "C" int emu_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs, uint32_t n,
                        uint64_t n_sims, uint64_t sim_offset, uint64_t seed, unsigned long long *hist,
@@ -43,23 +94,16 @@ extern "C" int emu_run(const mcgp_config *cfg, const mcgp_drivers *drv, const do
     blockIdx = {0, 0, 0};
     blockDim = {1, 1, 1};
     gridDim = {1, 1, 1};
-    switch (n) {
-#define X(N_)                                                                                                      \
-    case N_: {                                                                                                     \
-        /* one block at a time; inside a block the three phases of the kernel run for every "thread" in turn */   \
-        constexpr uint32_t B = mcgp::RegGeo<N_>::B;                                                                \
-        const uint32_t n_batches = (uint32_t)((n_sims + B - 1) / B);                                               \
-        for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N_>(&kp, mcgp::smem, t);                            \
-        for (uint32_t t = 0; t < B; ++t)                                                                           \
-            mcgp::reg_simulate<N_>(&kp, mcgp::smem, t, 0u, 1u, n_sims, sim_offset, (uint32_t)seed,                 \
-                                   (uint32_t)(seed >> 32), orders, fixed_grid, n_batches);                         \
-        for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N_>(mcgp::smem, t, hist);                            \
-        return 0;                                                                                                  \
+    int r = -1;
+    switch (EMU_PARTS > 1 ? n % EMU_PARTS : 0) {
+        case 0: r = emu_run_part0(&kp, n, n_sims, sim_offset, seed, hist, orders, fixed_grid); break;
+#if EMU_PARTS == 4
+        case 1: r = emu_run_part1(&kp, n, n_sims, sim_offset, seed, hist, orders, fixed_grid); break;
+        case 2: r = emu_run_part2(&kp, n, n_sims, sim_offset, seed, hist, orders, fixed_grid); break;
+        case 3: r = emu_run_part3(&kp, n, n_sims, sim_offset, seed, hist, orders, fixed_grid); break;
+#endif
     }
-        EMU_SIZES(X)
-#undef X
-        default:
-            *err = "no register instantiation for this field size";
-            return -1;
-    }
+    if (r != 0) *err = "no register instantiation for this field size";
+    return r;
 }
+#endif
