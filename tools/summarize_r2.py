@@ -137,6 +137,15 @@ def main():
                      f"{k.get('VGPR_Count')} | {ms:.2f} | {w['sims_per_launch'] / (ms * 1e-3):.3g} | {per('SQ_INSTS_VALU')} / {per('SQ_INSTS_SALU')} / {per('SQ_INSTS_LDS')} | "
                      f"{f2('active_lane_ratio')} | {f2('valu_busy', '{:.1%}')} | {f2('valu_issue_frac_of_peak')} | {f2('issue_frac')} / {f2('wait_frac')} | "
                      f"{f2('shader_clock_ghz')} | {f2('hbm_bytes_per_launch', '{:.3g}')} | {conflict:.3f} |" if ms else f'| {name} | incomplete |')
+    lines += ['', 'Columns: "VALU / SALU / LDS per wave-lap" = SQ_INSTS_* per launch / (simulations / 64) / laps; "active lanes" = '
+              'SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64; "VALUBusy" = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); '
+              '"VALU issue frac of peak" = SQ_INSTS_VALU / kernel time / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction); '
+              'HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB, separate passes (gfx950 correction for FETCH_SIZE).  '
+              f'`VGPR` is rocprofv3\'s VGPR_Count = allocated registers / 2 (225 -> 232 -> 116 for N = 20).', '',
+              f'Companion files: `{tag}_ablate.txt` (tools/ablate.sh: DUP = section run twice, SKIP = section left out; kernel ms at 4e6 '
+              f'simulations), `{tag}_inst_microbench.json` (tools/inst_microbench.hip: shader cycles per wave64 instruction per SIMD at 1, 2, 3 '
+              f'and ~8 waves per SIMD), `{tag}_deep_parity.txt` (tools/deep_parity.py), `{tag}_<workload>_kernel_stats.csv` '
+              '(verbatim `--kernel-trace --stats`).']
     with open(os.path.join(OUT, f'{tag}_summary.md'), 'w') as f:
         f.write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
