@@ -17,7 +17,7 @@
 // The block size is a compile-time function of N (RegGeo<N>::B), so every LDS address is
 // "bit field of pk | lane offset" + an immediate:
 //   per-lane rows (row stride = B: bank = f(lane) only, conflict-free gathers by driver index)
-//     Z    [N + 4][B] u32   this lap's deviate per DRIVER (NaN = the DNF draw hit); later the overtake draw words
+//     Z    [>= N][B]  u32   this lap's deviate per DRIVER (NaN = the DNF draw hit); later the overtake draw words
 //     LAST [N][B]     f64   last lap time per DRIVER                 (reference CarState.last_lap_time)
 //   block-shared tables: inverse-normal cubic, per-driver {variance, base pace, degradation},
 //     per-(driver, compound) {degradation x factor, pit threshold}, per-compound pace delta,
@@ -68,7 +68,10 @@ constexpr int k3GposShift = 27;                // [27..31] grid slot (most signi
 // ---- launch geometry and LDS map, fixed per field size ----
 constexpr size_t kLdsPerCu = 160 * 1024;       // gfx950
 __host__ __device__ constexpr size_t align16(size_t x) { return (x + 15) / 16 * 16; }
-__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)(n + 4) * 4 + (size_t)n * 8; }
+// rows of the per-lane Z plane: one per driver, and enough for the overtake draw words of one pass (whole Philox
+// blocks: 4 ceil((n - 1) / 4) words for at most n - 1 attempts)
+__host__ __device__ constexpr int z_rows_reg(int n) { return n > 4 * ((n + 2) / 4) ? n : 4 * ((n + 2) / 4); }
+__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)z_rows_reg(n) * 4 + (size_t)n * 8; }
 // block-shared tables: inverse-normal rows, per-driver {var, base} and {base, deg} (the latter with a second
 // half of NaNs that the pk word of a RETIRED car indexes: its pace is NaN, so both pairs it belongs to fail
 // every overtake test without a flag test), per-(compound, driver) {eff f64, opt u32, pad} for the 5 compounds,
@@ -109,8 +112,8 @@ struct RegGeo {
     static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}
     static constexpr uint32_t oHist = oDrs + 32;                  // u32[N x N]
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
-    static constexpr uint32_t oZ = oGrid + N * N * 8;             // [N + 4][B] u32
-    static constexpr uint32_t oLast = oZ + (uint32_t)(N + 4) * B * 4;  // [N][B] f64
+    static constexpr uint32_t oZ = oGrid + N * N * 8;             // [z_rows_reg(N)][B] u32
+    static constexpr uint32_t oLast = oZ + (uint32_t)z_rows_reg(N) * B * 4;  // [N][B] f64
     static constexpr uint32_t kBytes = oLast + (uint32_t)N * B * 8;
     static_assert(oZ == shared_lds_bytes_reg(N) && oLast % 8 == 0, "LDS map");
     static_assert(kBytes == per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N), "LDS map");
