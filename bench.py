@@ -14,12 +14,16 @@ per step when N > 1).  Simulations shard over ranks by global simulation id with
 no other exchange ("weak" scaling: per-GPU work is fixed).
 
 The JSON line printed by rank 0 carries, besides the contract fields,
-  roofline      algorithmic HBM bytes (20 B per simulation) / measured
-                kernel time, against the 8 TB/s HBM peak -- evidence that the path
-                is NOT memory bound; the binding resource is VALU issue, reported
-                in "valu" as simulated car-laps per second
-  cpu_baseline  the CPU oracle (C restatement, Mersenne-Twister back-end = the
-                reference-equivalent path) timed on one host core on a bounded sample
+  roofline       algorithmic HBM bytes (20 B per simulation) / live kernel time (hipEvents on the
+                 launch stream) against the 8 TB/s HBM peak, with `traffic` = HBM bytes per launch from the PMC
+                 passes -- evidence that the path is NOT memory bound
+  roofline_valu  the binding resource: wave-level VALU instructions per launch (PMC) / live kernel time against
+                 1024 SIMDs x 2.4 GHz / 2 cycles; counters are quoted only when profiles/r2_counters.json carries
+                 the source hash of the loaded library (else null, reason in roofline.counters_note)
+  workloads.S78  BASELINE configs[2] (78-lap Monaco parameters), three steps in the same run        (N = 1 only)
+  orders_mode    the same workload with the 20 B per simulation actually written                    (N = 1 only)
+  cpu_baseline   the CPU oracle on this box's host cores, bounded samples: MT back-end on one core (the
+                 reference-equivalent path) and Philox back-end on every core of the job's share; nproc, CPU model
 """
 import argparse
 import ctypes as C
