@@ -28,7 +28,7 @@ def test_fuzzed_configurations():
     with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
         cases = json.load(f)
     for name, c in cases.items():
-        if not (2 <= len(c["grid_probs"]) <= 32):
+        if not (1 <= len(c["grid_probs"]) <= 32):
             continue                                   # field sizes served by the generic LDS kernel
         ref = O.Problem(c).run(300, rng=O.RNG_PHILOX, seed=c['seed'], want_orders=True)
         hist, orders = K.run(c, 300, c['seed'])
@@ -66,7 +66,7 @@ def test_inverse_normal_transform_matches_the_oracle_word_for_word():
         assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), hex(w)
 
 
-@pytest.mark.parametrize('n', [2, 5, 13, 25, 28, 32])
+@pytest.mark.parametrize('n', [1, 2, 5, 13, 25, 28, 32])
 def test_field_sizes_up_to_the_abi_maximum(n):
     """Every register instantiation is the same source; sizes beyond the golden / fuzz cases, with an all-zero
     grid column (uniform fallback, reference :126-129) and per-driver spreads."""
