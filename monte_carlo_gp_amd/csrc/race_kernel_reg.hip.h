@@ -84,15 +84,24 @@ __host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
     return (size_t)kNormalRows * 16 + 3 * (size_t)kMaxCars * 16 + (size_t)kNumCompounds * kMaxCars * 16 +
            kCompStride * 16 + 32 + align16((size_t)n * n * 4) + (size_t)n * n * 8;
 }
+// Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this).  Two for the full
+// fields (LDS -- the LAST rows -- allows no more); small fields leave room for more, and more resident waves pay
+// even at the price of a few spilled registers (N = 10, same box: 45.4 ms at 3 waves, 43.3 ms at 4).
+#ifdef MCGP_MIN_WAVES
+__host__ __device__ constexpr int reg_min_waves(int) { return MCGP_MIN_WAVES; }
+#else
+__host__ __device__ constexpr int reg_min_waves(int n) { return n <= 10 ? 4 : n <= 13 ? 3 : 2; }
+#endif
 // Waves per block: the (waves per block, blocks per CU) pair that keeps the most waves resident within the
-// LDS budget at the kernel's 2 waves per SIMD (8 per CU); among equals at least 4 waves per block (fewer
-// copies of the shared tables), then the smaller block.
+// LDS budget and the kernel's waves per SIMD; among equals at least 4 waves per block (fewer copies of the
+// shared tables), then the smaller block.
 __host__ __device__ constexpr int reg_block_waves(int n)
 {
+    const int cap = 4 * reg_min_waves(n);
     int best = 0, waves = 1;
     for (int w = 1; w <= 8; ++w) {
         int b = (int)(kLdsPerCu / (shared_lds_bytes_reg(n) + (size_t)w * 64 * per_thread_lds_bytes_reg(n)));
-        if (b * w > 8) b = 8 / w;
+        if (b * w > cap) b = cap / w;
         if (b >= 1 && (b * w > best || (b * w == best && waves < 4))) { best = b * w; waves = w; }
     }
     return waves;
@@ -366,9 +375,6 @@ __device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uin
     }
 }
 
-#ifndef MCGP_MIN_WAVES
-#define MCGP_MIN_WAVES 2
-#endif
 #ifndef MCGP_PREPASS_BLOCKS
 #define MCGP_PREPASS_BLOCKS 2
 #endif
@@ -928,7 +934,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 }
 
 template <int N>
-__global__ void __launch_bounds__(RegGeo<N>::B, MCGP_MIN_WAVES)
+__global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                 uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
