@@ -104,3 +104,23 @@ def test_cli_backtest_world2_equals_world1(tmp_path):
     poles = [max(r['pole'], key=r['pole'].get) for r in one['races']]
     assert one['races'][0]['pole'] != one['races'][-1]['pole']
     assert len(set(tuple(sorted(r['pole'].items())) for r in one['races'])) > 12, poles
+
+
+def test_bench_two_ranks_sharing_the_gpu(tmp_path):
+    """bench.py's N > 1 path end to end (rank offsets, per-step histogram reduce, MAX-over-ranks timing, rank-0 JSON),
+    launched the way the driver launches it, with the two ranks sharing GPU 0 over gloo (MCGP_BENCH_SHARE_GPU=1:
+    RCCL refuses two ranks on one device; the RCCL branch itself needs a multi-GPU node)."""
+    env = dict(os.environ, MCGP_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--sims-per-step', '300000']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['config']['sims_per_gpu_per_step'] == 300000 and 'cpu_baseline' not in d
+    # the win probabilities come from 2 ranks x 2 steps x 3e5 = 1.2e6 simulations of S60: VER wins ~54 %
+    assert abs(d['win_probability_top3']['VER'] - 0.5445) < 0.005
