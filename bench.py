@@ -206,7 +206,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # MCGP_FORCE_PROCESS_GROUP=1: create the process group and run the per-step all-reduce even at world size 1
+    # (exercises the RCCL branch on a one-GPU box).  Never set by the driver.
+    from monte_carlo_gp_amd.distributed import wants_process_group
+    grouped = wants_process_group(world)
+    if grouped:
         if share:
             dist.init_process_group('gloo')
         else:
@@ -216,7 +220,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -242,7 +246,7 @@ def main():
                                         seed, local_rank, C.c_void_p(stream.cuda_stream),
                                         C.c_void_p(d_step.data_ptr()),
                                         C.c_void_p(d_orders.data_ptr()) if with_orders else None))
-            if world > 1:
+            if grouped:
                 if share:
                     h = d_step.cpu()
                     dist.all_reduce(h)
@@ -267,7 +271,7 @@ def main():
             kernel_ms.append(ms.value)
         sync()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if grouped:
             t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -307,6 +311,7 @@ def main():
             'value': r['total'] / r['elapsed'],
             'unit': 'race-simulations/s',
             'n_gpus': world,
+            'process_group': (dist.get_backend() if grouped else None),
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': r['elapsed'] / args.steps * 1e3,
@@ -350,7 +355,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -108,7 +108,8 @@ int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
  * multi-GPU path (RCCL all-reduce of d_hist) and by bench.py.  The small
  * parameter block is uploaded on the same stream before the launch; a block cached
  * from an earlier call on ANOTHER stream is re-used only behind an event wait on
- * that upload.  Runs of 2^32 simulations or more are split into several launches
+ * that upload, and is overwritten (4 blocks are cached) only after the launches of
+ * EVERY stream that used it have completed.  Runs of 2^32 simulations or more are split into several launches
  * on the stream (the per-block histogram counts in 32 bits). */
 int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs,
                         uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
@@ -143,13 +144,19 @@ int32_t mcgp_run_from_ratings(const mcgp_config *cfg, const mcgp_drivers *drv, c
                               uint64_t sim_offset, uint64_t seed, int32_t device, uint64_t *hist_out,
                               double *grid_probs_out);
 
-/* Measurement hooks (bench.py): duration in ms of the race kernel(s) of the MOST
- * RECENT mcgp_run / mcgp_run_device / mcgp_simulate_race call on `device` -- by any
- * thread: the timing events belong to the device context, not to the caller -- from
- * hipEvents recorded on that call's launch stream (synchronises on the stop event);
- * and the launch geometry that call used.  Meaningful when one thread drives the
- * device, which is how bench.py uses it. */
+/* Measurement hooks (bench.py): duration in ms of the race kernel(s) of a call, from
+ * hipEvents the library records on the call's launch stream around its launches
+ * (the query synchronises on the stop event).  Every stream keeps its own pair of
+ * events, so calls on different streams of one device do not disturb each other:
+ *   mcgp_stream_kernel_ms  the most recent call launched on `stream` (NULL = the
+ *                          default stream, which is where mcgp_run and
+ *                          mcgp_simulate_race launch); the library remembers the 8
+ *                          most recently used streams per device;
+ *   mcgp_last_kernel_ms    the most recent call on `device` by any thread --
+ *                          meaningful when one thread drives the device.
+ * mcgp_last_launch_info / mcgp_last_kernel_name describe that same most recent call. */
 int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out);
+int32_t mcgp_stream_kernel_ms(int32_t device, void *stream, float *ms_out);
 int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads,
                               uint32_t *lds_bytes);
 const char *mcgp_last_kernel_name(int32_t device);   /* "" before the first launch */

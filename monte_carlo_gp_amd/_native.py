@@ -89,10 +89,62 @@ def build(force=False):
     return LIB_PATH
 
 
+def hip_runtimes_mapped():
+    """Paths of the libamdhip64 copies mapped into this process (one in a healthy process)."""
+    paths = set()
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                if 'libamdhip64' in line:
+                    paths.add(line.split(None, 5)[-1].strip())
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def _bind_hip_runtime():
+    """Make libmcgp_hip.so and PyTorch share ONE HIP runtime, whichever is loaded first.
+
+    libmcgp_hip.so needs `libamdhip64.so.7` (found in /opt/rocm through its RUNPATH); PyTorch-ROCm ships its own
+    copy and asks for it as `libamdhip64.so`, a name the loader does not match against an already mapped
+    /opt/rocm copy.  Library first, torch second therefore maps two runtimes, and the second one finds no GPU
+    ("No HIP GPUs are available"); a hipStream_t of one handed to the other is undefined behaviour.  So when a
+    torch installation is present (located without importing it) and no runtime is mapped yet, map ITS copy
+    globally first: the library's NEEDED entry then binds to it by SONAME, and a later `import torch` finds
+    the same file.  MCGP_HIP_RUNTIME=system skips this (torch-free deployments), or names a libamdhip64 to use."""
+    if hip_runtimes_mapped():
+        return
+    choice = os.environ.get('MCGP_HIP_RUNTIME', '')
+    if choice == 'system':
+        return
+    cand = choice
+    if not cand:
+        import importlib.util
+        try:
+            spec = importlib.util.find_spec('torch')
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def assert_single_hip_runtime():
+    """Raise if this process has ended up with two HIP runtimes (library loaded against one, torch.cuda on another)."""
+    mapped = hip_runtimes_mapped()
+    if len(mapped) > 1:
+        raise McgpError(-3, 'two HIP runtimes are mapped into this process (' + ', '.join(mapped) + '): '
+                        'streams and device state cannot be shared between them; import torch before '
+                        'loading the library or set MCGP_HIP_RUNTIME')
+
+
 _lib = None
 
 EXPORTS = ('mcgp_abi_version', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
            'mcgp_simulate_race', 'mcgp_grid_probs', 'mcgp_run_from_ratings', 'mcgp_last_kernel_ms',
+           'mcgp_stream_kernel_ms',
            'mcgp_last_launch_info', 'mcgp_last_kernel_name')
 
 
@@ -104,7 +156,9 @@ def lib():
         if not path:
             build()
             path = LIB_PATH
+        _bind_hip_runtime()
         L = C.CDLL(path)
+        assert_single_hip_runtime()
         L.mcgp_abi_version.restype = C.c_int32
         L.mcgp_device_count.restype = C.c_int32
         L.mcgp_last_error.restype = C.c_char_p
@@ -131,6 +185,9 @@ def lib():
                                                 C.POINTER(C.c_uint64), dp]
         L.mcgp_last_kernel_ms.restype = C.c_int32
         L.mcgp_last_kernel_ms.argtypes = [C.c_int32, C.POINTER(C.c_float)]
+        if 'mcgp_stream_kernel_ms' not in missing:
+            L.mcgp_stream_kernel_ms.restype = C.c_int32
+            L.mcgp_stream_kernel_ms.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
         L.mcgp_last_kernel_name.restype = C.c_char_p
         L.mcgp_last_kernel_name.argtypes = [C.c_int32]
         L.mcgp_last_launch_info.restype = C.c_int32

@@ -166,7 +166,8 @@ def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, p
         rows.append((i, dict(race=entry['race'], season=season, laps=circuit_info(entry['race'])['laps'],
                              pole=res['pole_probabilities'], win=res['win_probabilities'],
                              podium_probabilities=res['podium_probabilities'], actual=entry)))
-    if world > 1:
+    from .distributed import wants_process_group
+    if wants_process_group(world):
         import torch.distributed as dist
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)
@@ -192,7 +193,9 @@ def cmd_backtest(args) -> int:
     share = os.environ.get('MCGP_BENCH_SHARE_GPU') == '1'
     if share:
         device = args.device
-    if world > 1:
+    from .distributed import wants_process_group
+    grouped = wants_process_group(world)
+    if grouped:
         from . import _native
         _native.lib()                     # build / load once before any rank touches the GPU
         import torch
@@ -216,7 +219,7 @@ def cmd_backtest(args) -> int:
         if args.json:
             with open(args.json, 'w') as f:
                 json.dump(res, f)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     return 0
 

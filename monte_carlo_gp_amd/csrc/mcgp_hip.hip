@@ -72,6 +72,8 @@ grid_probs_kernel(const double *__restrict__ in, const int32_t *__restrict__ pen
 }
 
 constexpr int kParamSlots = 4;
+constexpr int kSlotReaders = 8;        // streams with a launch in flight on one parameter block
+constexpr int kStreamTimers = 8;       // streams whose most recent call keeps its own timing events
 
 struct DeviceCtx {
     std::mutex mu;
@@ -84,7 +86,13 @@ struct DeviceCtx {
     struct Slot {
         mcgp::KParams *dev = nullptr;
         mcgp::KParams *host = nullptr;        // pinned copy of what `dev` holds
-        hipEvent_t done = nullptr;            // recorded after the last launch that reads `dev`
+        // one completion event per STREAM that has launched on this block: eviction waits for every one of
+        // them (a single event re-recorded by the latest stream would forget a reader still running elsewhere)
+        struct Reader {
+            hipStream_t stream = nullptr;
+            hipEvent_t done = nullptr;        // recorded after that stream's last launch reading `dev`
+            bool live = false;
+        } reader[kSlotReaders];
         hipEvent_t uploaded = nullptr;        // recorded after the upload of `dev`; other streams wait on it
         hipStream_t upload_stream = nullptr;
         bool used = false;
@@ -99,8 +107,16 @@ struct DeviceCtx {
     double *d_fe_out = nullptr;
     uint8_t *d_orders = nullptr;              // staging for mcgp_run(orders_out), grown on demand, kept
     size_t d_orders_bytes = 0;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
+    // timing events per stream (most recent call on that stream), so that calls on different streams of one
+    // device do not re-record each other's events
+    struct Timer {
+        hipStream_t stream = nullptr;
+        hipEvent_t start = nullptr, stop = nullptr;
+        bool used = false;
+        uint64_t seq = 0;
+    } timer[kStreamTimers];
+    uint64_t timer_seq = 0;
+    int last_timer = -1;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     char last_kernel[48] = "";
 };
@@ -131,7 +147,8 @@ void release_ctx(DeviceCtx &c)
     for (auto &sl : c.slot) {
         if (sl.dev) (void)hipFree(sl.dev);
         if (sl.host) (void)hipHostFree(sl.host);
-        if (sl.done) (void)hipEventDestroy(sl.done);
+        for (auto &rd : sl.reader)
+            if (rd.done) (void)hipEventDestroy(rd.done);
         if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
         sl = DeviceCtx::Slot{};
     }
@@ -144,12 +161,15 @@ void release_ctx(DeviceCtx &c)
     c.d_fe_in = c.d_fe_out = nullptr;
     c.d_fe_pen = nullptr;
     if (c.d_orders) (void)hipFree(c.d_orders);
-    if (c.ev_start) (void)hipEventDestroy(c.ev_start);
-    if (c.ev_stop) (void)hipEventDestroy(c.ev_stop);
+    for (auto &t : c.timer) {
+        if (t.start) (void)hipEventDestroy(t.start);
+        if (t.stop) (void)hipEventDestroy(t.stop);
+        t = DeviceCtx::Timer{};
+    }
+    c.last_timer = -1;
     c.d_hist = nullptr;
     c.d_grid = c.d_order1 = c.d_orders = nullptr;
     c.d_orders_bytes = 0;
-    c.ev_start = c.ev_stop = nullptr;
 }
 
 int init_ctx_body(int device, DeviceCtx &c)
@@ -162,7 +182,6 @@ int init_ctx_body(int device, DeviceCtx &c)
     for (auto &sl : c.slot) {
         HIP_TRY(hipMalloc(&sl.dev, sizeof(mcgp::KParams)));
         HIP_TRY(hipHostMalloc(&sl.host, sizeof(mcgp::KParams)));
-        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
     }
     HIP_TRY(hipMalloc(&c.d_hist, sizeof(unsigned long long) * MCGP_MAX_CARS * MCGP_MAX_CARS));
@@ -171,8 +190,6 @@ int init_ctx_body(int device, DeviceCtx &c)
     HIP_TRY(hipMalloc(&c.d_fe_in, sizeof(double) * 4 * MCGP_MAX_CARS));
     HIP_TRY(hipMalloc(&c.d_fe_pen, sizeof(int32_t) * MCGP_MAX_CARS));
     HIP_TRY(hipMalloc(&c.d_fe_out, sizeof(double) * MCGP_MAX_CARS * MCGP_MAX_CARS));
-    HIP_TRY(hipEventCreate(&c.ev_start));
-    HIP_TRY(hipEventCreate(&c.ev_stop));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
 #define X(N_)                                                                                         \
@@ -323,7 +340,12 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     if (!sl) {
         sl = &c.slot[c.next_slot];
         c.next_slot = (c.next_slot + 1) % kParamSlots;
-        if (sl->used) HIP_TRY(hipEventSynchronize(sl->done));   // its last reader has finished
+        if (sl->used)                                           // every stream that read it has finished
+            for (auto &rd : sl->reader)
+                if (rd.live) {
+                    HIP_TRY(hipEventSynchronize(rd.done));
+                    rd.live = false;
+                }
         std::memcpy(sl->host, &kp, sizeof(kp));
         sl->used = true;
         sl->shareable = !fe.on;
@@ -342,7 +364,25 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         // cached block uploaded on another stream: order this stream behind that upload
         HIP_TRY(hipStreamWaitEvent(stream, sl->uploaded, 0));
     }
-    HIP_TRY(hipEventRecord(c.ev_start, stream));
+    // this stream's timing events (its most recent call); the least recently used entry is recycled
+    int ti = -1;
+    for (int i = 0; i < kStreamTimers; ++i)
+        if (c.timer[i].used && c.timer[i].stream == stream) { ti = i; break; }
+    if (ti < 0) {
+        ti = 0;
+        for (int i = 0; i < kStreamTimers; ++i) {
+            if (!c.timer[i].used) { ti = i; break; }
+            if (c.timer[i].seq < c.timer[ti].seq) ti = i;
+        }
+        if (!c.timer[ti].start) {
+            HIP_TRY(hipEventCreate(&c.timer[ti].start));
+            HIP_TRY(hipEventCreate(&c.timer[ti].stop));
+        }
+        c.timer[ti].stream = stream;
+        c.timer[ti].used = true;
+    }
+    c.timer[ti].seq = ++c.timer_seq;
+    HIP_TRY(hipEventRecord(c.timer[ti].start, stream));
     const uint64_t cap = max_sims_per_launch();
     uint32_t grid = 0, block = 0, lds = 0;
     for (uint64_t done = 0; done < n_sims; done += cap) {
@@ -355,9 +395,27 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
                            (uint32_t)n_batches);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(c.ev_stop, stream));
-    HIP_TRY(hipEventRecord(sl->done, stream));
-    c.timed = true;
+    HIP_TRY(hipEventRecord(c.timer[ti].stop, stream));
+    c.last_timer = ti;
+    {
+        // completion event of (this block, this stream)
+        DeviceCtx::Slot::Reader *rd = nullptr, *spare = nullptr;
+        for (auto &r : sl->reader) {
+            if (r.live && r.stream == stream) { rd = &r; break; }
+            if (!r.live && !spare) spare = &r;
+        }
+        if (!rd) {
+            if (!spare) {                               // more streams in flight than entries: retire the first
+                spare = &sl->reader[0];
+                HIP_TRY(hipEventSynchronize(spare->done));
+            }
+            rd = spare;
+            if (!rd->done) HIP_TRY(hipEventCreateWithFlags(&rd->done, hipEventDisableTiming));
+            rd->stream = stream;
+            rd->live = true;
+        }
+        HIP_TRY(hipEventRecord(rd->done, stream));
+    }
     c.last_grid = grid;
     c.last_block = block;
     c.last_lds = lds;
@@ -496,7 +554,12 @@ static int upload_front_end(DeviceCtx &c, const double *rating, const double *te
     if (n < 1 || n > MCGP_MAX_CARS) return fail(MCGP_E_BAD_ARG, "n must be in [1, 32]");
     double in[4 * MCGP_MAX_CARS];
     for (uint32_t d = 0; d < n; ++d) {
-        if (!(rating[d] == rating[d])) return fail(MCGP_E_BAD_ARG, "a quali rating is NaN");
+        // a non-finite input makes the softmax (inf - inf) or the row adjustments NaN: the race kernel would then
+        // sample uniform grids silently, where mcgp_run rejects such a matrix
+        if (!std::isfinite(rating[d]) || !std::isfinite(teammate_delta[d]) || !std::isfinite(form_score[d]) ||
+            !std::isfinite(circuit_affinity[d]))
+            return fail(MCGP_E_BAD_ARG, "a front-end input (rating / teammate_delta / form_score / circuit_affinity) "
+                                        "is not finite");
         in[d] = rating[d];
         in[n + d] = teammate_delta[d];
         in[2 * n + d] = form_score[d];
@@ -561,7 +624,8 @@ int32_t mcgp_run_from_ratings(const mcgp_config *cfg, const mcgp_drivers *drv, c
         HIP_TRY(hipMemcpy(h, c->d_hist, hist_bytes, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n * n; ++i) hist_out[i] += h[i];
         if (grid_probs_out) {
-            // the matrix the race kernel sampled from: read back from the parameter block it was written into
+            // the matrix the race kernel sampled from, recomputed by the same kernel from the same inputs into the
+            // context's scratch matrix (the parameter block itself is not read back)
             hipLaunchKernelGGL(grid_probs_kernel, dim3(1), dim3(mcgp::kMaxCars), 0, nullptr, c->d_fe_in, c->d_fe_pen, (int)n,
                                c->d_fe_out);
             HIP_TRY(hipGetLastError());
@@ -580,11 +644,28 @@ int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out)
     if (device < 0 || device >= kMaxDevices) return fail(MCGP_E_BAD_ARG, "device index out of range");
     DeviceCtx &c = g_ctx[device];
     std::lock_guard<std::mutex> lock(c.mu);
-    if (!c.ready || !c.timed) return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
+    if (!c.ready || c.last_timer < 0) return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipEventSynchronize(c.ev_stop));
-    HIP_TRY(hipEventElapsedTime(ms_out, c.ev_start, c.ev_stop));
+    HIP_TRY(hipEventSynchronize(c.timer[c.last_timer].stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, c.timer[c.last_timer].start, c.timer[c.last_timer].stop));
     return MCGP_OK;
+}
+
+int32_t mcgp_stream_kernel_ms(int32_t device, void *stream, float *ms_out)
+{
+    if (!ms_out) return fail(MCGP_E_BAD_ARG, "ms_out is NULL");
+    if (device < 0 || device >= kMaxDevices) return fail(MCGP_E_BAD_ARG, "device index out of range");
+    DeviceCtx &c = g_ctx[device];
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (!c.ready) return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
+    for (auto &t : c.timer)
+        if (t.used && t.stream == (hipStream_t)stream) {
+            HIP_TRY(hipSetDevice(device));
+            HIP_TRY(hipEventSynchronize(t.stop));
+            HIP_TRY(hipEventElapsedTime(ms_out, t.start, t.stop));
+            return MCGP_OK;
+        }
+    return fail(MCGP_E_BAD_ARG, "no timed launch on this stream (or its entry was recycled by 8 newer streams)");
 }
 
 const char *mcgp_last_kernel_name(int32_t device)
@@ -595,7 +676,7 @@ const char *mcgp_last_kernel_name(int32_t device)
 
 int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads, uint32_t *lds_bytes)
 {
-    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready || !g_ctx[device].timed)
+    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready || g_ctx[device].last_timer < 0)
         return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
     if (grid_blocks) *grid_blocks = g_ctx[device].last_grid;
     if (block_threads) *block_threads = g_ctx[device].last_block;

@@ -71,7 +71,12 @@ __host__ __device__ constexpr size_t align16(size_t x) { return (x + 15) / 16 * 
 // rows of the per-lane Z plane: one per driver, and enough for the overtake draw words of one pass (whole Philox
 // blocks: 4 ceil((n - 1) / 4) words for at most n - 1 attempts)
 __host__ __device__ constexpr int z_rows_reg(int n) { return n > 4 * ((n + 2) / 4) ? n : 4 * ((n + 2) / 4); }
-__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)z_rows_reg(n) * 4 + (size_t)n * 8; }
+#ifdef MCGP_HACK_LDS3      // TIMING EXPERIMENT ONLY (wrong results): LAST rows aliased 8-way so that 3 waves per SIMD fit
+__host__ __device__ constexpr int last_rows_reg(int n) { return n < 8 ? n : 8; }
+#else
+__host__ __device__ constexpr int last_rows_reg(int n) { return n; }
+#endif
+__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)z_rows_reg(n) * 4 + (size_t)last_rows_reg(n) * 8; }
 // block-shared tables: inverse-normal rows, per-driver {var, base} and {base, deg} (the latter with a second
 // half of NaNs that the pk word of a RETIRED car indexes: its pace is NaN, so both pairs it belongs to fail
 // every overtake test without a flag test), per-(compound, driver) {eff f64, opt u32, pad} for the 5 compounds,
@@ -123,7 +128,7 @@ struct RegGeo {
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
     static constexpr uint32_t oZ = oGrid + N * N * 8;             // [z_rows_reg(N)][B] u32
     static constexpr uint32_t oLast = oZ + (uint32_t)z_rows_reg(N) * B * 4;  // [N][B] f64
-    static constexpr uint32_t kBytes = oLast + (uint32_t)N * B * 8;
+    static constexpr uint32_t kBytes = oLast + (uint32_t)last_rows_reg(N) * B * 8;
     static_assert(oZ == shared_lds_bytes_reg(N) && oLast % 8 == 0, "LDS map");
     static_assert(kBytes == per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N), "LDS map");
     static_assert(kBytes <= kLdsPerCu, "block does not fit LDS");
@@ -460,7 +465,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 
     // per-lane rows by ABSOLUTE LDS address (race_isa.hip.h): a compile-time row is an immediate offset ...
     auto z_row = [&](int d) -> uint32_t { return G::oZ + (uint32_t)d * (B * 4) + tid4; };
-    auto l_row = [&](int d) -> uint32_t { return G::oLast + (uint32_t)d * (B * 8) + tid8; };
+    auto l_row = [&](int d) -> uint32_t { return G::oLast + (uint32_t)(d % last_rows_reg(N)) * (B * 8) + tid8; };
     // ... and the row of the driver held in a pk word is one and-or (B = 256); the f64 row sits at twice that offset
     auto row4 = [&](uint32_t p) -> uint32_t {
         if constexpr (B == 256) return (p & k3IdMask) | tid4;
@@ -485,12 +490,18 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         uint32_t opt;
         double last, var, base, eff, cdelta, drs;
         uint32_t a4;            // byte offset of the driver's Z row (the LAST row is at twice that)
+        uint32_t la;
     };
     auto load_slot = [&](uint32_t p) -> SlotIn {
         SlotIn r;
         r.a4 = row4(p);
         r.z = lds_ld<float>(G::oZ + r.a4);
-        r.last = lds_ld<double>(G::oLast + (r.a4 << 1));
+#ifdef MCGP_HACK_LDS3
+        r.la = ((p >> k3IdShift) & 7u) * (uint32_t)(B * 8) + tid8;
+#else
+        r.la = r.a4 << 1;
+#endif
+        r.last = lds_ld<double>(G::oLast + r.la);
         const uint32_t id16 = (p >> 6) & 0x1F0u;                                  // 16 x driver
         const uint32_t ic = id16 + ((p & k3CompMask) << 2);                       // 16 x (32 compound + driver)
         const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);
@@ -782,7 +793,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         // x + 0.0 == x for the finite, non-negative times here: cars that do not run keep their time
                         const double t = cum[i] + (run ? lap_time : 0.0);
                         cum[i] = t + (pit ? pit_loss : 0.0);                                        // :464
-                        lds_st<double>(G::oLast + (s.a4 << 1), lap_time);                                                      // :219
+                        lds_st<double>(G::oLast + s.la, lap_time);                                  // :219
                     }
                 }
             }

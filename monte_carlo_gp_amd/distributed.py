@@ -9,7 +9,16 @@ tuning is needed, and it is the path's only exchange.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
+
+def wants_process_group(world: int) -> bool:
+    """A run is distributed when it has more than one rank -- or when MCGP_FORCE_PROCESS_GROUP=1 asks for the
+    process group and its collectives even at world size 1 (how the RCCL code path is exercised on a one-GPU
+    box: RCCL admits one rank per device)."""
+    return world > 1 or os.environ.get('MCGP_FORCE_PROCESS_GROUP') == '1'
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -26,10 +35,12 @@ def all_reduce_histogram(hist: np.ndarray, device=None, group=None) -> np.ndarra
     """Sum an integer histogram over all ranks of the default (or given) process group."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or not wants_process_group(dist.get_world_size(group)):
         return hist
     t = torch.from_numpy(np.ascontiguousarray(hist.astype(np.int64)))
     if dist.get_backend(group) == 'nccl':
+        from . import _native
+        _native.assert_single_hip_runtime()       # torch.cuda and the library must share one HIP runtime
         t = t.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()

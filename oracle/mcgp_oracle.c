@@ -224,6 +224,40 @@ float orc_normal_from_u32(uint32_t w)
     return (w >> 31) ? -z : z;
 }
 
+/* ---- 53-bit refinement of the counter-based deviates (MCGP_ORACLE_RNG_PHILOX53) ----
+ * The reference draws 53-bit uniforms (genrand_res53) and exact normals (reference :137,194,302,330,524);
+ * the product draws 32-bit words.  This back-end measures what that substitution does, by COMMON RANDOM
+ * NUMBERS: every draw keeps the word w the 32-bit back-end reads (same Philox address) as its leading 32
+ * bits and takes 21 more from a companion block (counter word 3 | 0x8000, same word position):
+ *     uniform  u53 = (w 2^21 + e) / 2^53                  in [w / 2^32, (w + 1) / 2^32)
+ *     normal   sign = w >> 31, m = w & 0x7fffffff, tail probability p = (m 2^21 + e + 0.5) / 2^53
+ *              (the 32-bit draw's (m + 0.5) / 2^32 refined), z = -+ Phi^-1(p) in binary64
+ *              (Halley steps on libm erfc from the table value, |err| ~ 1e-16)
+ * so a race simulated with both back-ends differs only by the refinement itself.  Not matched by any GPU
+ * code; used by tools/deviate_bias.py and tests/test_oracle_golden.py only. */
+static double phi_inverse_tail(uint64_t q53, float z_start)
+{
+    /* p = (q53 + 0.5) / 2^53 in (0, 0.5): lower-tail probability; returns z = Phi^-1(p) < 0.
+     * Newton on F(z) = erfc(-z / sqrt 2) / 2 (erfc of a positive argument: full relative accuracy in the
+     * tail), started from the product's own piecewise cubic (|err| <= 4.8e-7): two steps reach binary64. */
+    const double p = ((double)q53 + 0.5) * 0x1p-53;
+    double z = (double)z_start;
+    if (z > -1e-300) z = -1e-300;
+    /* two steps suffice from the table value; only the cells of the 16 smallest m, which span decades of
+     * p, start far away and take more */
+    for (int it = 0; it < 100; it++) {
+        const double F = 0.5 * erfc(-z * 0.70710678118654752440);
+        const double pdf = 0.39894228040143267794 * exp(-0.5 * z * z);
+        const double d = (F - p) / pdf;
+        const double step = d / (1.0 + 0.5 * z * d);  /* Halley correction: F'' / F' = -z */
+        z = z - step;
+        if (fabs(step) <= 1e-16 * fabs(z)) break;
+    }
+    return z;
+}
+
+double orc_phi_inverse_tail(uint64_t q53, float z_start) { return phi_inverse_tail(q53, z_start); }
+
 /* ------------------------------------------------------------------------- */
 /* Random source seen by the race logic.  The logic asks for draws in the      */
 /* reference's order; the MT back-end answers from its streams, the Philox     */
@@ -256,39 +290,64 @@ static uint32_t philox_word(const rng_t *r, uint32_t lap, uint32_t purpose, uint
 
 static inline double u32_to_unit(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
 
+/* the 21 refinement bits of a draw: top bits of the same word of the companion block */
+static uint32_t philox_extra21(const rng_t *r, uint32_t lap, uint32_t purpose, uint32_t index, int word)
+{
+    return philox_word(r, lap, purpose, 0x8000u | index, word) >> 11;
+}
+/* uniform of the draw at (lap, purpose, index, word) under the back-end in use (Philox family only) */
+static double philox_uniform(const rng_t *r, uint32_t lap, uint32_t purpose, uint32_t index, int word)
+{
+    const uint32_t w = philox_word(r, lap, purpose, index, word);
+    if (r->mode != MCGP_ORACLE_RNG_PHILOX53) return u32_to_unit(w);
+    const uint64_t q = ((uint64_t)w << 21) | philox_extra21(r, lap, purpose, index, word);
+    return (double)q * 0x1p-53;
+}
+/* standard normal of the draw at that address */
+static double philox_normal(const rng_t *r, uint32_t lap, uint32_t purpose, uint32_t index, int word)
+{
+    const uint32_t w = philox_word(r, lap, purpose, index, word);
+    const float z32 = orc_normal_from_u32(w);
+    if (r->mode != MCGP_ORACLE_RNG_PHILOX53) return (double)z32;
+    const uint64_t q = ((uint64_t)(w & 0x7fffffffu) << 21) | philox_extra21(r, lap, purpose, index, word);
+    /* tail probability (m + 0.5) / 2^32 of the 32-bit draw refined to (q + 0.5) / 2^53 */
+    const double z0 = phi_inverse_tail(q, (w >> 31) ? -z32 : z32);
+    return (w >> 31) ? -z0 : z0;
+}
+
 static double draw_grid(rng_t *r, int slot)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->np);          /* :137 choice */
-    return u32_to_unit(philox_word(r, 0, PURPOSE_GRID, (uint32_t)slot >> 2, slot & 3));
+    return philox_uniform(r, 0, PURPOSE_GRID, (uint32_t)slot >> 2, slot & 3);
 }
 static double draw_event(rng_t *r, int lap, int which)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :168,171,174,392 */
-    return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_EVENT, 0, which));
+    return philox_uniform(r, (uint32_t)lap, PURPOSE_EVENT, 0, which);
 }
 static double draw_dnf(rng_t *r, int lap, int driver)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :194,287 */
-    if (lap == 1) return u32_to_unit(philox_word(r, 1u, PURPOSE_CAR, (uint32_t)driver, 0));
-    return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1)));
+    if (lap == 1) return philox_uniform(r, 1u, PURPOSE_CAR, (uint32_t)driver, 0);
+    return philox_uniform(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1));
 }
 static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :524 */
-    return u32_to_unit(philox_word(r, (uint32_t)lap, PURPOSE_OVT, (uint32_t)(8 * pass + (attempt >> 2)), attempt & 3));
+    return philox_uniform(r, (uint32_t)lap, PURPOSE_OVT, (uint32_t)(8 * pass + (attempt >> 2)), attempt & 3);
 }
 /* np.random.normal(0, scale) */
 static double draw_lap_noise(rng_t *r, int lap, int driver, double scale)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return orc_mt_np_normal(r->mt, 0.0, scale);   /* :330 */
-    const uint32_t w = lap == 1 ? philox_word(r, 1u, PURPOSE_CAR, (uint32_t)driver, 1)
-                                : philox_word(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1) + 1);
-    return 0.0 + scale * (double)orc_normal_from_u32(w);
+    const double z = lap == 1 ? philox_normal(r, 1u, PURPOSE_CAR, (uint32_t)driver, 1)
+                              : philox_normal(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1) + 1);
+    return 0.0 + scale * z;
 }
 static double draw_start_delta(rng_t *r, int driver, double scale)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return orc_mt_np_normal(r->mt, 0.0, scale);   /* :302 */
-    return 0.0 + scale * (double)orc_normal_from_u32(philox_word(r, 1u, PURPOSE_CAR, (uint32_t)driver, 2));
+    return 0.0 + scale * philox_normal(r, 1u, PURPOSE_CAR, (uint32_t)driver, 2);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -702,7 +761,7 @@ static int check_args(const orc_config *cfg, const orc_drivers *drv, int32_t n, 
     if (!cfg || !drv || n < 1 || n > MCGP_ORACLE_MAX_CARS) return -1;
     if (cfg->total_laps < 1 || cfg->total_laps > 32767) return -1;
     if (rng == MCGP_ORACLE_RNG_MT && !mt) return -1;
-    if (rng != MCGP_ORACLE_RNG_MT && rng != MCGP_ORACLE_RNG_PHILOX) return -1;
+    if (rng != MCGP_ORACLE_RNG_MT && rng != MCGP_ORACLE_RNG_PHILOX && rng != MCGP_ORACLE_RNG_PHILOX53) return -1;
     return 0;
 }
 

@@ -16,6 +16,11 @@
  *   MCGP_ORACLE_RNG_PHILOX  counter-based Philox4x32-10, every draw addressed by
  *                           (seed, simulation id, lap, purpose, index); the HIP
  *                           kernel must match this back-end EXACTLY.
+ *   MCGP_ORACLE_RNG_PHILOX53 the same draws refined to the reference's deviate precision: each
+ *                           uniform keeps the 32-bit word as its leading bits and takes 21 more from a
+ *                           companion Philox block; each normal is the binary64 inverse normal CDF at
+ *                           that 53-bit point.  Run beside PHILOX on the same (seed, simulation id) it
+ *                           measures what the product's 32-bit deviates change (tools/deviate_bias.py).
  */
 #ifndef MCGP_ORACLE_H
 #define MCGP_ORACLE_H
@@ -28,6 +33,7 @@ extern "C" {
 #define MCGP_ORACLE_MAX_CARS 32
 #define MCGP_ORACLE_RNG_MT 0
 #define MCGP_ORACLE_RNG_PHILOX 1
+#define MCGP_ORACLE_RNG_PHILOX53 2   /* PHILOX refined to 53-bit uniforms / binary64 normals (common random numbers) */
 
 enum { ORC_SOFT = 0, ORC_MEDIUM = 1, ORC_HARD = 2, ORC_INTERMEDIATE = 3, ORC_WET = 4 };
 enum { ORC_DRY = 0, ORC_DAMP = 1, ORC_WET_TRACK = 2 };
@@ -86,6 +92,8 @@ int orc_mt_np_choice(orc_mt_state *, const double *p, int n);      /* np.random.
 /* Philox helpers exposed for unit tests. */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 float orc_normal_from_u32(uint32_t w);
+/* Phi^-1((q53 + 0.5) / 2^53) for q53 < 2^52 (lower tail), Newton from z_start; exposed for unit tests. */
+double orc_phi_inverse_tail(uint64_t q53, float z_start);
 
 /* Run n_sims simulations.
  *   grid_probs  n x n row-major [driver][slot]

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, 'libmcgp_oracle.so')
 COMPOUNDS = ['SOFT', 'MEDIUM', 'HARD', 'INTERMEDIATE', 'WET']
 COMPOUND_ID = {c: i for i, c in enumerate(COMPOUNDS)}
 TRACK_ID = {'dry': 0, 'damp': 1, 'wet': 2}
-RNG_MT, RNG_PHILOX = 0, 1
+RNG_MT, RNG_PHILOX, RNG_PHILOX53 = 0, 1, 2
 
 
 class OrcConfig(C.Structure):
@@ -49,7 +49,7 @@ class OrcTrace(C.Structure):
 
 def build(force=False):
     """Compile the oracle if the shared object is missing or stale."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ('mcgp_oracle.c', 'mcgp_oracle.h', 'normal_table.h')]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ('mcgp_oracle.c', 'mcgp_oracle.h', 'normal_table.h', 'frontend_exp.h', 'Makefile')]
     if (force or not os.path.exists(LIB_PATH)
             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.check_call(['make', '-C', ORACLE_DIR, '-s', '-B'], stdout=subprocess.DEVNULL,
@@ -78,6 +78,8 @@ def lib():
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_normal_from_u32.restype = C.c_float
         L.orc_normal_from_u32.argtypes = [C.c_uint32]
+        L.orc_phi_inverse_tail.restype = C.c_double
+        L.orc_phi_inverse_tail.argtypes = [C.c_uint64, C.c_float]
         L.orc_run.restype = C.c_int
         L.orc_run.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcDrivers), C.POINTER(C.c_double), C.c_int32,
                               C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,

@@ -124,3 +124,62 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     assert d['config']['sims_per_gpu_per_step'] == 300000 and 'cpu_baseline' not in d
     # the win probabilities come from 2 ranks x 2 steps x 3e5 = 1.2e6 simulations of S60: VER wins ~54 %
     assert abs(d['win_probability_top3']['VER'] - 0.5445) < 0.005
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The RCCL branch on the one GPU there is: a world-size-1 `nccl` group (RCCL admits one rank per device), with
+# MCGP_FORCE_PROCESS_GROUP=1 keeping the process group and its collectives although nothing needs reducing.
+# ---------------------------------------------------------------------------------------------------------
+_NCCL1 = {'MCGP_FORCE_PROCESS_GROUP': '1', 'MCGP_BENCH_SHARE_GPU': '0', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'}
+
+
+def test_library_first_then_torch_cuda_share_one_hip_runtime(tmp_path):
+    """run_monte_carlo BEFORE torch.cuda is touched, then torch's current stream and a side
+    stream into mcgp_run_device, then all_reduce_histogram's device branch -- one HIP runtime throughout."""
+    out = tmp_path / 'rt.npz'
+    n_sims, seed = 30000, 42
+    _run_ranks(1, lambda r: ['runtime', out, n_sims, seed], extra_env=_NCCL1)
+    got = np.load(out)
+    ref = O.Problem(O.load_case('S60')).run(n_sims, rng=O.RNG_PHILOX, seed=seed)['hist']
+    for k in ('first', 'current', 'side', 'reduced'):
+        assert np.array_equal(got[k], ref), k
+
+
+def test_run_monte_carlo_sharded_through_rccl_world1(tmp_path):
+    """distributed.run_monte_carlo_sharded with a real `nccl` process group (one rank): the int64 histogram is
+    all-reduced ON THE DEVICE by RCCL and the result is the oracle's."""
+    name, n_total, seed = 'S78', 50_000, 7
+    out = tmp_path / 'h.npy'
+    _run_ranks(1, lambda r: ['nccl1', out, name, n_total, seed], extra_env=_NCCL1)
+    ref = O.Problem(O.load_case(name)).run(n_total, rng=O.RNG_PHILOX, seed=seed)['hist']
+    assert np.array_equal(np.load(out), ref)
+
+
+def test_cli_backtest_through_rccl_world1(tmp_path):
+    """`cli backtest` with the nccl group created (one rank): all_gather_object over RCCL; same scores as without."""
+    n_sims, seed = 20000, 42
+    _run_ranks(1, lambda r: ['backtest', tmp_path / 'nccl.json', n_sims, seed], extra_env=_NCCL1)
+    _run_ranks(1, lambda r: ['backtest', tmp_path / 'plain.json', n_sims, seed], extra_env={'WORLD_SIZE': '1'})
+    with open(tmp_path / 'nccl.json') as f:
+        a = json.load(f)
+    with open(tmp_path / 'plain.json') as f:
+        b = json.load(f)
+    assert a['n_races'] == b['n_races'] == 24
+    for k in ('pole_brier', 'win_brier', 'podium_accuracy'):
+        assert a[k] == b[k], k
+
+
+def test_bench_through_rccl_world1(tmp_path):
+    """bench.py's N > 1 code path on RCCL: `nccl` process group, per-step int64 all_reduce on the launch stream,
+    barrier + MAX-over-ranks timing -- at world size 1, launched through torch.distributed.run like the driver does."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MCGP_FORCE_PROCESS_GROUP='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MCGP_BENCH_SHARE_GPU'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '1', '--steps', '3',
+           '--warmup', '1', '--sims-per-step', '1000000', '--no-cpu-baseline', '--no-extras']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['process_group'] == 'nccl' and d['value'] > 0
+    assert abs(d['win_probability_top3']['VER'] - 0.5445) < 0.005

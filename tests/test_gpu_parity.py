@@ -183,56 +183,86 @@ def test_long_runs_split_into_launches(require_gpu, monkeypatch):
     assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
 
 
-def test_cached_parameter_block_across_streams(require_gpu):
-    """mcgp_run_device on stream A, then the same problem on stream B and on the NULL stream: the cached
-    parameter block is re-used behind an event wait on its upload.  Streams and buffers come
-    straight from the HIP runtime the library itself is linked against (no second runtime in the process)."""
+def _device_problem(name, pit_loss_shift=0.0):
+    """(case, dense problem, grid matrix); pit_loss_shift makes a problem no earlier test can have left in the
+    library's parameter-block cache."""
+    import copy
+    from monte_carlo_gp_amd.simulation import _Problem, RaceSimulator
+    from monte_carlo_gp_amd import RaceConfig
+    case = copy.deepcopy(O.load_case(name))
+    case['config']['pit_loss'] += pit_loss_shift
+    drivers = list(case['grid_probs'])
+    p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'],
+                 case['driver_variance'], case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
+    return case, p, RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+
+
+def _run_on_stream(p, g, n_sims, seed, stream, d_hist, offset=0):
     import ctypes as C
     from monte_carlo_gp_amd import _native as N
-    from monte_carlo_gp_amd.simulation import _Problem, _dptr, RaceSimulator
-    from monte_carlo_gp_amd import RaceConfig
-    N.lib()
-    # the HIP runtime this process already has mapped (the one libmcgp_hip.so resolved against; a process that
-    # imported torch first carries torch's bundled copy): never load a second one
-    with open('/proc/self/maps') as f:
-        paths = sorted({line.split()[-1] for line in f if 'libamdhip64' in line})
-    assert paths, 'libmcgp_hip.so is loaded but no libamdhip64 is mapped?'
-    hip = C.CDLL(paths[0])
+    from monte_carlo_gp_amd.simulation import _dptr
+    N.check(N.lib().mcgp_run_device(C.byref(p.cfg), C.byref(p.drv), _dptr(g), p.n, n_sims, offset, seed, 0,
+                                    C.c_void_p(stream.cuda_stream), C.c_void_p(d_hist.data_ptr()), None))
 
-    def ok(rc):
-        assert rc == 0, f'HIP error {rc}'
-    ok(hip.hipSetDevice(0))
-    streams = []
-    for _ in range(2):
-        st = C.c_void_p()
-        ok(hip.hipStreamCreateWithFlags(C.byref(st), 1))          # hipStreamNonBlocking
-        streams.append(st)
-    streams.append(C.c_void_p(0))                                 # the NULL stream
+
+def test_cached_parameter_block_across_streams(require_gpu):
+    """mcgp_run_device on torch stream A, then the same problem on stream B and on torch's current stream: the
+    cached parameter block is re-used behind an event wait on its upload.  The library was loaded
+    BEFORE torch in this process (require_gpu); both use one HIP runtime (_native._bind_hip_runtime)."""
+    import torch
+    from monte_carlo_gp_amd import _native as N
+    assert len(N.hip_runtimes_mapped()) == 1, N.hip_runtimes_mapped()
+    dev = torch.device('cuda', 0)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream(dev)]
     for name, seed in (('EVT', 5), ('DMP', 6), ('HET', 7), ('S50', 8), ('N10', 9)):       # more problems than cache slots
-        case = O.load_case(name)
-        drivers = list(case['grid_probs'])
-        p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'],
-                     case['driver_variance'], case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
-        g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
-        nbytes = p.n * p.n * 8
-        bufs = []
-        for _ in streams:
-            d = C.c_void_p()
-            ok(hip.hipMalloc(C.byref(d), C.c_size_t(nbytes)))
-            ok(hip.hipMemset(d, 0, C.c_size_t(nbytes)))
-            bufs.append(d)
-        ok(hip.hipDeviceSynchronize())
+        case, p, g = _device_problem(name)
+        bufs = [torch.zeros(p.n * p.n, dtype=torch.int64, device=dev) for _ in streams]
+        torch.cuda.synchronize(dev)
         for st, d in zip(streams, bufs):
-            N.check(N.lib().mcgp_run_device(C.byref(p.cfg), C.byref(p.drv), _dptr(g), p.n, 5000, 0, seed, 0, st, d, None))
-        ok(hip.hipDeviceSynchronize())
+            _run_on_stream(p, g, 5000, seed, st, d)
+        torch.cuda.synchronize(dev)
         ref = O.Problem(case).run(5000, rng=O.RNG_PHILOX, seed=seed)['hist']
         for d in bufs:
-            h = np.zeros((p.n, p.n), np.uint64)
-            ok(hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), d, C.c_size_t(nbytes), 2))      # device -> host
-            ok(hip.hipFree(d))
-            assert np.array_equal(h.astype(np.int64), ref), name
-    for st in streams[:2]:
-        ok(hip.hipStreamDestroy(st))
+            assert np.array_equal(d.cpu().numpy().reshape(p.n, p.n), ref), name
+
+
+def test_parameter_block_eviction_waits_for_every_stream(require_gpu):
+    """VERDICT r2 item 6.  Stream A runs a long launch (1e7 simulations) on problem P0; stream B then uses the SAME
+    cached block for a short launch, and goes on through four more problems, which evicts P0's block while A's
+    kernel is still reading it.  With one completion event per block (re-recorded by B) the eviction would wait for
+    B only and overwrite the block under A; with one event per (block, stream) A's result is intact.  Per-stream
+    timing: A's and B's kernel times are both readable afterwards and differ by the 1000x in work."""
+    import ctypes as C
+    import torch
+    from monte_carlo_gp_amd import _native as N
+    dev = torch.device('cuda', 0)
+    A, B = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    case0, p0, g0 = _device_problem('S60', 0.125)            # never seen before: takes a fresh cache slot
+    big, small = 10_000_000, 10_000
+    dA = torch.zeros(p0.n * p0.n, dtype=torch.int64, device=dev)
+    dB = torch.zeros(p0.n * p0.n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    _run_on_stream(p0, g0, big, 42, A, dA)                   # ~0.1 s of kernel, asynchronous
+    _run_on_stream(p0, g0, small, 42, B, dB)                 # same block, other stream
+    others = []
+    for name, seed in (('EVT', 5), ('DMP', 6), ('HET', 7), ('S50', 8), ('N10', 9)):       # 5 more new problems > 4 slots
+        case, p, g = _device_problem(name, 0.25)
+        d = torch.zeros(p.n * p.n, dtype=torch.int64, device=dev)
+        _run_on_stream(p, g, 3000, seed, B, d)
+        others.append((name, case, p, d, seed))
+    msA, msB = C.c_float(), C.c_float()
+    N.check(N.lib().mcgp_stream_kernel_ms(0, C.c_void_p(A.cuda_stream), C.byref(msA)))
+    N.check(N.lib().mcgp_stream_kernel_ms(0, C.c_void_p(B.cuda_stream), C.byref(msB)))
+    torch.cuda.synchronize(dev)
+    assert msA.value > 20 * msB.value > 0, (msA.value, msB.value)
+    hA = dA.cpu().numpy().reshape(p0.n, p0.n)
+    assert (hA.sum(axis=0) == big).all() and (hA.sum(axis=1) == big).all()
+    # A's run equals the same run made alone (a block overwritten under it would change the parameters mid-flight)
+    alone = product_run(case0, big, 42)[0]
+    assert np.array_equal(hA, alone)
+    assert np.array_equal(dB.cpu().numpy().reshape(p0.n, p0.n), O.Problem(case0).run(small, rng=O.RNG_PHILOX, seed=42)['hist'])
+    for name, case, p, d, seed in others:
+        assert np.array_equal(d.cpu().numpy().reshape(p.n, p.n), O.Problem(case).run(3000, rng=O.RNG_PHILOX, seed=seed)['hist']), name
 
 
 def test_orders_into_an_unaligned_device_buffer(require_gpu):

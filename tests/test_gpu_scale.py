@@ -36,7 +36,7 @@ def test_full_size_run_properties(require_gpu, name, n_sims):
 def test_statistical_link_to_reference_mt(require_gpu, name):
     """Link 3: HIP-Philox vs the REFERENCE's own MT runs (tests/golden/ref_stat_*.npz, 2e5 / 1e5 sims).
 
-    Tolerance: every histogram cell within 4.5 binomial standard errors of the reference sample
+    Tolerance: every histogram cell within 4 binomial standard errors of the reference sample
     (+1e-4 absolute for cells with a handful of counts); win probabilities within the same band.
     """
     ref = np.load(O.GOLDEN_DIR + f'/ref_stat_{name}.npz')
@@ -47,7 +47,7 @@ def test_statistical_link_to_reference_mt(require_gpu, name):
     p_gpu = hist / n_gpu
     se = np.sqrt(np.maximum(p_gpu * (1 - p_gpu), 1e-12) * (1 / n_ref + 1 / n_gpu))
     z = np.abs(p_gpu - p_ref) / (se + 1e-12)
-    bad = np.argwhere(np.abs(p_gpu - p_ref) > 4.5 * se + 1e-4)
+    bad = np.argwhere(np.abs(p_gpu - p_ref) > 4.0 * se + 1e-4)
     assert bad.size == 0, f'{name}: cells {bad[:5].tolist()} off, max z {z.max():.2f}'
     # chi-square over all n*n cells with enough counts: a global shape check
     mask = p_ref * n_ref >= 50
@@ -70,15 +70,15 @@ def test_statistical_link_oracle_mt_large(require_gpu):
     hist, _, _ = product_run(case, n_gpu, 99)
     p_mt, p_gpu = h_mt / n_mt, hist / n_gpu
     se = np.sqrt(np.maximum(p_gpu * (1 - p_gpu), 1e-12) * (1 / n_mt + 1 / n_gpu))
-    assert np.all(np.abs(p_mt - p_gpu) <= 4.5 * se + 5e-5), float(np.max(np.abs(p_mt - p_gpu) / (se + 1e-12)))
-    assert abs(p_mt[0, 0] - p_gpu[0, 0]) < 4.5 * se[0, 0]          # VER win probability
+    assert np.all(np.abs(p_mt - p_gpu) <= 4.0 * se + 5e-5), float(np.max(np.abs(p_mt - p_gpu) / (se + 1e-12)))
+    assert abs(p_mt[0, 0] - p_gpu[0, 0]) < 4.0 * se[0, 0]          # VER win probability
 
 
 @pytest.mark.parametrize('name', ['S50', 'EVT', 'HET', 'DMP', 'N10'])
 def test_statistical_link_other_cases(require_gpu, name):
     """Link 3 on the remaining golden configurations (event storm, heterogeneous 21-car field,
     rain, 10-car field, the set.pop()-sensitive 50-lap race): 2e5 oracle-MT simulations (8 seeds)
-    against 1e7 HIP-Philox simulations, every cell within 4.5 SE + 1e-4."""
+    against 1e7 HIP-Philox simulations, every cell within 4 SE + 1e-4."""
     from concurrent.futures import ThreadPoolExecutor
     case = O.load_case(name)
 
@@ -92,4 +92,58 @@ def test_statistical_link_other_cases(require_gpu, name):
     p_mt, p_gpu = h_mt / n_mt, hist / n_gpu
     se = np.sqrt(np.maximum(p_gpu * (1 - p_gpu), 1e-12) * (1 / n_mt + 1 / n_gpu))
     worst = float(np.max(np.abs(p_mt - p_gpu) / (se + 1e-12)))
-    assert np.all(np.abs(p_mt - p_gpu) <= 4.5 * se + 1e-4), (name, worst)
+    assert np.all(np.abs(p_mt - p_gpu) <= 4.0 * se + 1e-4), (name, worst)
+
+
+def test_configs3_one_billion_simulations_as_eight_shards(require_gpu):
+    """BASELINE configs[3]'s workload on the one GPU there is: S60, N = 1e9, seed 42, as the 8 contiguous
+    shard_range pieces an 8-GPU launch gives its ranks, run back to back through mcgp_run_device (one launch each)
+    and summed the way the all-reduce sums them (reference src/simulation.py:83-100: independent simulations,
+    counts added).  Checked through size-independent properties: Latin-square histogram, an oracle slice
+    straddling the rank-3 / rank-4 seam, and -- at 1e8 -- equality of three different partitions."""
+    import ctypes as C
+    import torch
+    from monte_carlo_gp_amd import RaceConfig, _native as N
+    from monte_carlo_gp_amd.distributed import shard_range
+    from monte_carlo_gp_amd.simulation import RaceSimulator, _Problem, _dptr
+    case = O.load_case('S60')
+    drivers = list(case['grid_probs'])
+    p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
+                 case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
+    g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.current_stream(dev)
+    n, seed = p.n, 42
+
+    def run_partition(n_total, world):
+        total = torch.zeros(n * n, dtype=torch.int64, device=dev)
+        seams = []
+        for rank in range(world):
+            off, cnt = shard_range(n_total, rank, world)
+            seams.append(off)
+            part = torch.zeros(n * n, dtype=torch.int64, device=dev)            # this rank's histogram
+            N.check(N.lib().mcgp_run_device(C.byref(p.cfg), C.byref(p.drv), _dptr(g), n, cnt, off, seed, 0,
+                                            C.c_void_p(stream.cuda_stream), C.c_void_p(part.data_ptr()), None))
+            total += part                                                       # what all_reduce(SUM) does
+        torch.cuda.synchronize(dev)
+        return total.cpu().numpy().reshape(n, n), seams
+
+    N_TOTAL = 1_000_000_000
+    hist, seams = run_partition(N_TOTAL, 8)
+    assert seams == [r * 125_000_000 for r in range(8)]
+    assert (hist.sum(axis=0) == N_TOTAL).all() and (hist.sum(axis=1) == N_TOTAL).all()
+    # VER's win probability from 1e9 simulations against the 2e7-simulation value of the statistical tests
+    assert abs(hist[0, 0] / N_TOTAL - 0.5445) < 0.002
+    # oracle slice straddling the seam between rank 3 and rank 4
+    seam = seams[4]
+    _, _, orders = product_run(case, 4096, seed, sim_offset=seam - 2048, orders=True)
+    ref = O.Problem(case).run(4096, rng=O.RNG_PHILOX, seed=seed, sim_offset=seam - 2048, want_orders=True)
+    assert np.array_equal(orders, ref['orders'])
+    # three partitions of 1e8: one piece, eight shards, three ragged shards
+    a, _ = run_partition(100_000_000, 1)
+    b, _ = run_partition(100_000_000, 8)
+    c, _ = run_partition(100_000_000, 3)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    # and the first 1e8 of the big run are those simulations: ranks 0..7 of 1e9 cover [0, 1e9) contiguously, so the
+    # 1e8 histogram must be dominated cell by cell by the 1e9 one
+    assert (a <= hist).all()

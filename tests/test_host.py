@@ -119,3 +119,31 @@ def test_seed_resolution():
     a = RaceSimulator._resolve_seed(None)
     random.seed(123)
     assert RaceSimulator._resolve_seed(None) == a       # a globally seeded run stays reproducible (Q20)
+
+
+def test_one_hip_runtime_whichever_is_loaded_first():
+    """libmcgp_hip.so (NEEDED libamdhip64.so.7, RUNPATH /opt/rocm) loaded before torch (which asks for
+    its bundled copy as `libamdhip64.so`) used to map TWO HIP runtimes; _native._bind_hip_runtime maps torch's copy
+    first.  Checked in fresh interpreters, both orders (no GPU needed: only the mappings are inspected); with the
+    binding switched off the library refuses to coexist silently -- assert_single_hip_runtime raises."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from monte_carlo_gp_amd import _native as N\n"
+            "order = sys.argv[1]\n"
+            "if order == 'torch_first':\n    import torch\n    N.lib()\n"
+            "else:\n    N.lib()\n    import torch\n"
+            "try:\n    N.assert_single_hip_runtime(); ok = 1\n"
+            "except N.McgpError: ok = 0\n"
+            "print(len(N.hip_runtimes_mapped()), ok)\n") % (str(__import__('os').path.dirname(N._PKG)),)
+    import os
+    env = {k: v for k, v in os.environ.items() if k != 'MCGP_HIP_RUNTIME'}
+    for order in ('lib_first', 'torch_first'):
+        out = subprocess.run([sys.executable, '-c', code, order], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.split() == ['1', '1'], (order, out.stdout)
+    if os.path.exists('/opt/rocm/lib/libamdhip64.so'):
+        out = subprocess.run([sys.executable, '-c', code, 'lib_first'], env=dict(env, MCGP_HIP_RUNTIME='system'),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.split() == ['2', '0'], out.stdout          # the failure mode, detected
