@@ -84,10 +84,10 @@ __device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
     const int sh = 27 - __clz((int)mm);                 // floor(log2 mm) - 4
     const uint32_t k = (mm >> sh) & 15u;
     const uint32_t r = mm & ((1u << sh) - 1u);
-    float t = ((float)r + 0.5f) * __uint_as_float((uint32_t)(127 - sh) << 23);
-    t = small ? 0.0f : t;                               // (the 16 tail rows are constants; measured: this form, which
-                                                        //  hipcc compiles to a never-skipped branch, is 0.8 % faster
-                                                        //  than the select-free one)
+    // (for m < 16 this t is 0.5 where the oracle uses 0: the 16 tail rows hold a constant, c1 = c2 = c3 = +0.0, and
+    //  fma(0, t, c) = c exactly, so no select -- which hipcc turns into a branch that cuts the caller's code into
+    //  basic blocks -- is needed)
+    const float t = ((float)r + 0.5f) * __uint_as_float((uint32_t)(127 - sh) << 23);
     const uint32_t row = small ? m : 16u + 16u * (uint32_t)sh + k;
     const float4 c = row_of(row);
     float z = __builtin_fmaf(c.w, t, c.z);

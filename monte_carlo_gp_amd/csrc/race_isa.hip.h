@@ -282,17 +282,39 @@ __device__ __forceinline__ f64x2 lds_ld_f64x2(uint32_t addr)             // one 
     const v2d v = *reinterpret_cast<const MCGP_LDS v2d *>(addr);
     return f64x2{v.x, v.y};
 }
-// {f64, u32, pad}: one ds_read_b128 (16-byte aligned address)
-__device__ __forceinline__ void lds_ld_f64_u32(uint32_t addr, double &d, uint32_t &u)
+// {f64, u32, u32}: one ds_read_b128 (16-byte aligned address)
+__device__ __forceinline__ void lds_ld_f64_u32x2(uint32_t addr, double &d, uint32_t &u0, uint32_t &u1)
 {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const v4u v = *reinterpret_cast<const MCGP_LDS v4u *>(addr);
     d = __hiloint2double((int)v.y, (int)v.x);
-    u = v.z;
+    u0 = v.z;
+    u1 = v.w;
 }
+
+// binary64 -> uint32 the way the hardware converts: toward zero, saturating at 0 and 2^32 - 1, NaN -> 0.
+// (A C++ cast is undefined outside the range; the draw-word thresholds of the overtake step rely on the clamp.)
+__device__ __forceinline__ uint32_t cvt_u32_f64_sat(double x)
+{
+    uint32_t r;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ double ceil_f64(double x) { return __builtin_ceil(x); }
+__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// w < (hi << 32 | lo) for a 32-bit w: one 64-bit compare
+__device__ __forceinline__ bool lt_u64(uint32_t w, uint32_t lo, uint32_t hi)
+{
+    return (uint64_t)w < (((uint64_t)hi << 32) | (uint64_t)lo);
+}
+// scheduling fence: the compiler's instruction scheduler moves nothing across it
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// true if the predicate holds in ANY lane of the wavefront (wave-uniform result)
+#define MCGP_ANY(pred) (__any((int)(pred)) != 0)
 // Keeps a value computed where it is written: the compiler may not sink its computation into one arm of a later
 // select and turn the select into a branch (no instruction is emitted).
 __device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
 
 // address of the dynamic LDS block as the hardware sees it
 __device__ __forceinline__ uint32_t lds_base_of(const void *p)

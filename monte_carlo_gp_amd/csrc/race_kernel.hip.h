@@ -261,7 +261,8 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                     const bool dec_age = sc || (vsc && (uint64_t)e3 < P->t_vsc_tire);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     int k = 0;
-                    double leader = 0.0;
+                    double leader = 0.0, prev_nt = -1.0;
+                    bool tie = false;
                     for (int i = 0; i < n; ++i) {
                         const uint32_t d = s.Ord(i);
                         uint32_t pk = s.Pk(d);
@@ -272,6 +273,8 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                         if (red) nt = leader + (double)k * 0.1;
                         else if (sc) nt = leader + (double)k * 0.5;
                         else { const double gap = t - leader; nt = leader + gap * 0.8; }
+                        tie |= nt == prev_nt;
+                        prev_nt = nt;
                         const double tbl = nt - leader;
                         pk &= ~kDirty;
                         if (tbl > 0 && tbl < dirty_thr) pk |= kDirty;
@@ -288,7 +291,9 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                         ++k;
                     }
                     drs_disabled_until = lap + (vsc ? 1 : 2);
-                    if (vsc) sort_by_time(s, n);   // x0.8 is monotone but may round two gaps together
+                    // x0.8 is monotone but may round two gaps together: equal times fall back to grid order.  Otherwise
+                    // the field order (`ord`, which also addresses this lap's draws) stays what the last lap left.
+                    if (tie) sort_by_time(s, n);
                 }
             }
 
@@ -305,8 +310,9 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                     const double ahead_last = carry;
                     carry = s.Last(d);
                     uint32_t w0, w1, w2, w3;
-                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (d >> 1), seed_lo, seed_hi, w0, w1, w2, w3);
-                    if (d & 1u) { w0 = w2; w1 = w3; }               // one block serves drivers 2j and 2j+1
+                    // draws are addressed by the car's place i in the field order: one block serves places 2j and 2j+1
+                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | ((uint32_t)i >> 1), seed_lo, seed_hi, w0, w1, w2, w3);
+                    if (i & 1) { w0 = w2; w1 = w3; }
                     if ((uint64_t)w0 < t_dnf[d]) {                  // :194-197
                         s.Pk(d) = (pk & ~kAgeMask) | kDnf | (uint32_t)lap;
                         continue;

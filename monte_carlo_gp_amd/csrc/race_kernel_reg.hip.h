@@ -14,18 +14,18 @@
 // (which only moves a few cars by 0.1-0.3 s).  Ties compare pk as an integer: the grid slot sits
 // in its top bits, which is Python's stable-sort order for the reference's grid-ordered lists.
 //
-// The block size is a compile-time function of N (RegGeo<N>::B), so every LDS address is
-// "bit field of pk | lane offset" + an immediate:
-//   per-lane rows (row stride = B: bank = f(lane) only, conflict-free gathers by driver index)
-//     Z    [>= N][B]  u32   this lap's deviate per DRIVER (NaN = the DNF draw hit); later the overtake draw words
-//     LAST [N][B]     f64   last lap time per DRIVER                 (reference CarState.last_lap_time)
-//   block-shared tables: inverse-normal cubic, per-driver {variance, base pace, degradation},
-//     per-(driver, compound) {degradation x factor, pit threshold}, per-compound pace delta,
-//     the n x n histogram (u32) and the transposed grid matrix.
+// Occupancy is what this kernel is short of (one wave issues an instruction every ~5 cycles whatever
+// it is; a SIMD needs 3+ waves to fill its issue slots), so the per-lane footprint is kept to what three
+// waves per SIMD admit at N = 20: <= 168 VGPRs and 192 B of LDS per lane
+//     LAST [N][B]  f64   last lap time per DRIVER                 (reference CarState.last_lap_time)
+//     W    [8][B]  u32   draw words of the overtake attempts of one pass (8 at a time)
+// with row stride = the block size B (bank = f(lane) only: conflict-free gathers by driver index), plus the
+// block-shared tables: inverse-normal cubic, per-driver {variance, base pace}, {base pace, degradation} x 2^31,
+// per-(compound, driver) {degradation x factor, pit threshold, DNF threshold}, per-compound pace delta, the
+// n x n histogram (u32) and the transposed grid matrix.
 //
-// Random draws: one Philox block per TWO drivers and lap (words: dnf, noise, dnf, noise),
-// generated in a driver-indexed pre-pass with wave-uniform thresholds, so the per-lap RNG
-// cost is N/2 + 1 Philox calls plus one per four overtake attempts.
+// Random draws of a lap are addressed by the car's PLACE in the field order (its register index): the block of
+// places 2j and 2j+1 is computed right where the two cars' laps are, and never touches LDS.
 #pragma once
 #include "race_common.hip.h"
 #include "race_isa.hip.h"
@@ -46,13 +46,16 @@
 #ifndef MCGP_STAT
 #define MCGP_STAT(what, value)
 #endif
+#ifndef MCGP_TRACE_PASS
+#define MCGP_TRACE_PASS(sim, lap, pass, n_cand)
+#endif
 
 namespace mcgp {
 
 // pk word of the register kernel.  Field positions are chosen so that LDS addresses fall out of one
-// mask or one shift + mask: (pk & 0x7C00) = driver << 10 = the byte offset of the driver's Z row when
-// B = 256; (pk >> 6) & 0x1F0 = 16 driver; (pk & 0x380) << 2 = 512 compound; (pk >> 3) & 0x70 = 16 compound;
-// pk & 0x10 = 16 drs.
+// mask or one shift + mask: (pk >> 6) & 0x1F0 = 16 driver; (pk >> 6) & 0x3F0 = 16 (32 dnf + driver);
+// (pk & 0x380) << 2 = 512 compound; (pk >> 3) & 0x70 = 16 compound; pk & 0x10 = 16 drs; and
+// (pk & k3AgeMask) + (1 << 16) = (tyre age + 1) << 16, which compares directly with the pit-stop word.
 constexpr uint32_t k3UsedMask = 7u;            // [0..2] dry compounds used so far (SOFT, MEDIUM, HARD)
 constexpr uint32_t k3Drs = 1u << 4;            // (pk & 0x10) = 16 drs: byte offset into the {0.0, drs_delta} table
 constexpr uint32_t k3Dirty = 1u << 5;          // 0 < time_behind_leader < dirty_air_threshold
@@ -68,44 +71,41 @@ constexpr int k3GposShift = 27;                // [27..31] grid slot (most signi
 // ---- launch geometry and LDS map, fixed per field size ----
 constexpr size_t kLdsPerCu = 160 * 1024;       // gfx950
 __host__ __device__ constexpr size_t align16(size_t x) { return (x + 15) / 16 * 16; }
-// rows of the per-lane Z plane: one per driver, and enough for the overtake draw words of one pass (whole Philox
-// blocks: 4 ceil((n - 1) / 4) words for at most n - 1 attempts)
-__host__ __device__ constexpr int z_rows_reg(int n) { return n > 4 * ((n + 2) / 4) ? n : 4 * ((n + 2) / 4); }
-#ifdef MCGP_HACK_LDS3      // TIMING EXPERIMENT ONLY (wrong results): LAST rows aliased 8-way so that 3 waves per SIMD fit
-__host__ __device__ constexpr int last_rows_reg(int n) { return n < 8 ? n : 8; }
-#else
-__host__ __device__ constexpr int last_rows_reg(int n) { return n; }
-#endif
-__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)z_rows_reg(n) * 4 + (size_t)last_rows_reg(n) * 8; }
-// block-shared tables: inverse-normal rows, per-driver {var, base} and {base, deg} (the latter with a second
-// half of NaNs that the pk word of a RETIRED car indexes: its pace is NaN, so both pairs it belongs to fail
-// every overtake test without a flag test), per-(compound, driver) {eff f64, opt u32, pad} for the 5 compounds,
-// per-compound {delta, pad}, {0.0, drs_delta}, n x n histogram (u32), transposed grid matrix (f64).  The driver
-// index varies fastest in every table (16-byte entries): lanes holding different drivers hit different banks,
-// the same driver broadcasts.
+// Rows of the per-lane W plane: the draw words of 8 overtake attempts (two Philox blocks).  A pass with more
+// attempts than that in some lane -- 0.4 % of wave-passes on the 20-car benchmark fields -- goes through the
+// plane 8 attempts at a time.  The same 32 bytes per lane hold the sampled grid (one byte per slot) before lap 1.
+constexpr int kWordRows = 8;
+__host__ __device__ constexpr size_t per_thread_lds_bytes_reg(int n) { return (size_t)kWordRows * 4 + (size_t)n * 8; }
+// block-shared tables: inverse-normal rows; per-driver {var, base}; {base, deg} x 2^31 with a second copy of
+// NaNs 32 entries further on, which the pk word of a RETIRED car indexes: its pace is NaN, so both pairs it
+// belongs to fail every overtake test without a flag test; per-(compound, driver) {eff f64, pit word u32, DNF
+// threshold u32} (compound stride 32 entries); per-compound {delta, pad}; {0.0, drs_delta} and the same x 2^31;
+// n x n histogram (u32); transposed grid matrix (f64).  The driver index varies fastest in every table (16-byte
+// entries): lanes holding different drivers hit different banks, the same driver broadcasts.  Tables end at the
+// last driver (not at 32): the LDS saved is what lets the N = 20 block hold three waves per SIMD.
 constexpr int kNumCompounds = 5;
 __host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
 {
-    return (size_t)kNormalRows * 16 + 3 * (size_t)kMaxCars * 16 + (size_t)kNumCompounds * kMaxCars * 16 +
-           kCompStride * 16 + 32 + align16((size_t)n * n * 4) + (size_t)n * n * 8;
+    return (size_t)kNormalRows * 16 + (size_t)n * 16 + (size_t)(kMaxCars + n) * 16 +
+           (size_t)((kNumCompounds - 1) * kMaxCars + n) * 16 + kCompStride * 16 + 64 + align16((size_t)n * n * 4) +
+           (size_t)n * n * 8;
 }
-// Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this).  Two for the full
-// fields (LDS -- the LAST rows -- allows no more); small fields leave room for more, and more resident waves pay
-// even at the price of a few spilled registers (N = 10, same box: 45.4 ms at 3 waves, 43.3 ms at 4).
+// Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this).
 #ifdef MCGP_MIN_WAVES
 __host__ __device__ constexpr int reg_min_waves(int) { return MCGP_MIN_WAVES; }
 #else
-__host__ __device__ constexpr int reg_min_waves(int n) { return n <= 10 ? 4 : n <= 13 ? 3 : 2; }
+__host__ __device__ constexpr int reg_min_waves(int n) { return n <= 10 ? 4 : n <= 21 ? 3 : 2; }
 #endif
 // Waves per block: the (waves per block, blocks per CU) pair that keeps the most waves resident within the
 // LDS budget and the kernel's waves per SIMD; among equals at least 4 waves per block (fewer copies of the
 // shared tables), then the smaller block.
+constexpr size_t kLdsReserve = 256;             // kept free: the block must fit beside what the runtime itself may take
 __host__ __device__ constexpr int reg_block_waves(int n)
 {
     const int cap = 4 * reg_min_waves(n);
     int best = 0, waves = 1;
-    for (int w = 1; w <= 8; ++w) {
-        int b = (int)(kLdsPerCu / (shared_lds_bytes_reg(n) + (size_t)w * 64 * per_thread_lds_bytes_reg(n)));
+    for (int w = 1; w <= 16; ++w) {
+        int b = (int)((kLdsPerCu - kLdsReserve) / (shared_lds_bytes_reg(n) + (size_t)w * 64 * per_thread_lds_bytes_reg(n)));
         if (b * w > cap) b = cap / w;
         if (b >= 1 && (b * w > best || (b * w == best && waves < 4))) { best = b * w; waves = w; }
     }
@@ -119,20 +119,21 @@ struct RegGeo {
     // block-shared tables first: their bases (and the row bases below) fit the 16-bit immediate offset of a DS
     // instruction, so an address is just the bit field taken from pk
     static constexpr uint32_t oNorm = 0;                          // float4[kNormalRows]
-    static constexpr uint32_t oDrvA = oNorm + kNormalRows * 16;   // {var, base} x 32 drivers, 16 B each   (lap step)
-    static constexpr uint32_t oDrvB = oDrvA + kMaxCars * 16;      // {base, deg} x 32 drivers + 32 x {NaN, NaN}  (overtake pace)
-    static constexpr uint32_t oIc = oDrvB + 2 * kMaxCars * 16;    // [compound][driver] {eff f64, opt u32, pad}, 16 B each
-    static constexpr uint32_t oComp = oIc + kNumCompounds * kMaxCars * 16;   // {delta f64, pad} x 8, 16 B each
-    static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}
-    static constexpr uint32_t oHist = oDrs + 32;                  // u32[N x N]
+    static constexpr uint32_t oDrvA = oNorm + kNormalRows * 16;   // {var, base} x N drivers, 16 B each   (lap step)
+    static constexpr uint32_t oDrvB = oDrvA + N * 16;             // {base, deg} 2^31 x N drivers; at +32 entries {NaN, NaN} x N  (overtake pace)
+    static constexpr uint32_t oIc = oDrvB + (kMaxCars + N) * 16;  // [compound][driver] {eff f64, pit word u32, DNF threshold u32}
+    static constexpr uint32_t oComp = oIc + ((kNumCompounds - 1) * kMaxCars + N) * 16;   // {delta f64, pad} x 8, 16 B each
+    static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}              (lap time)
+    static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, pad}, {drs_delta 2^31, pad}         (overtake pace)
+    static constexpr uint32_t oHist = oDrsB + 32;                 // u32[N x N]
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
-    static constexpr uint32_t oZ = oGrid + N * N * 8;             // [z_rows_reg(N)][B] u32
-    static constexpr uint32_t oLast = oZ + (uint32_t)z_rows_reg(N) * B * 4;  // [N][B] f64
-    static constexpr uint32_t kBytes = oLast + (uint32_t)last_rows_reg(N) * B * 8;
-    static_assert(oZ == shared_lds_bytes_reg(N) && oLast % 8 == 0, "LDS map");
+    static constexpr uint32_t oW = oGrid + N * N * 8;             // [kWordRows][B] u32
+    static constexpr uint32_t oLast = oW + (uint32_t)kWordRows * B * 4;      // [N][B] f64
+    static constexpr uint32_t kBytes = oLast + (uint32_t)N * B * 8;
+    static_assert(oW == shared_lds_bytes_reg(N) && oLast % 8 == 0, "LDS map");
     static_assert(kBytes == per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N), "LDS map");
-    static_assert(kBytes <= kLdsPerCu, "block does not fit LDS");
-    // (oLast < 65536 for N <= 20: the row bases then fit the DS immediate offset as well)
+    static_assert(kBytes + kLdsReserve <= kLdsPerCu, "block does not fit LDS");
+    static_assert(oLast < 65536, "row bases must fit the DS immediate offset");
 };
 
 // Knuth, TAOCP 5.2.2 Algorithm M (merge exchange): a sorting network for any N.  Comparators of one (p, q, r, d)
@@ -380,11 +381,15 @@ __device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uin
     }
 }
 
-#ifndef MCGP_PREPASS_BLOCKS
-#define MCGP_PREPASS_BLOCKS 2
+// The instruction scheduler may not move anything across this point (no instruction is emitted).
+#ifndef MCGP_SCHED_FENCE
+#define MCGP_SCHED_FENCE() sched_fence()
 #endif
 #ifndef MCGP_STEP_BATCH
-#define MCGP_STEP_BATCH 5          // slots whose LDS gathers are in flight together in the lap step
+#define MCGP_STEP_BATCH 4          // slots whose LDS gathers (and Philox blocks) are in flight together in the lap step
+#endif
+#ifndef MCGP_PACE_BATCH
+#define MCGP_PACE_BATCH 5          // slots whose pace gathers are in flight together in an overtake pass
 #endif
 
 // Phase 1 of a block: fill the block-shared LDS tables (all threads, strided).
@@ -398,29 +403,37 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
     double *t_grid = reinterpret_cast<double *>(smem + G::oGrid);          // [slot][driver]
     for (uint32_t i = tid; i < (uint32_t)kNormalRows * 4; i += B)
         reinterpret_cast<uint32_t *>(t_norm)[i] = P->normal_bits[i];
-    for (uint32_t d = tid; d < (uint32_t)kMaxCars; d += B) {
+    for (uint32_t d = tid; d < (uint32_t)N; d += B) {
         double *a = reinterpret_cast<double *>(smem + G::oDrvA + d * 16);
         double *b = reinterpret_cast<double *>(smem + G::oDrvB + d * 16);
         const double qnan = __builtin_nan("");
-        a[0] = d < (uint32_t)N ? P->variance[d] : 0.0;
-        a[1] = d < (uint32_t)N ? P->base_pace[d] : 0.0;
-        b[0] = d < (uint32_t)N ? P->base_pace[d] : 0.0;
-        b[1] = d < (uint32_t)N ? P->tire_deg[d] : 0.0;
-        b[2 * kMaxCars] = qnan;                                  // the retired half: pace = NaN
+        a[0] = P->variance[d];
+        a[1] = P->base_pace[d];
+        // overtake pace, scaled by 2^31 (exact: a power of two commutes with every rounding of base + age x deg):
+        // the pace delta then comes out as delta x 2^31, whose ceiling IS the integer threshold of the draw word
+        b[0] = P->base_pace[d] * 2147483648.0;
+        b[1] = P->tire_deg[d] * 2147483648.0;
+        b[2 * kMaxCars] = qnan;                                  // the retired copy: pace = NaN
         b[2 * kMaxCars + 1] = qnan;
     }
     if (tid < 2) {
         double *r = reinterpret_cast<double *>(smem + G::oDrs + tid * 16);
         r[0] = tid ? P->drs_delta : 0.0;
         r[1] = 0.0;
+        double *q = reinterpret_cast<double *>(smem + G::oDrsB + tid * 16);
+        q[0] = tid ? P->drs_delta * 2147483648.0 : 0.0;
+        q[1] = 0.0;
     }
     for (uint32_t i = tid; i < (uint32_t)kNumCompounds * N; i += B) {
         const uint32_t c = i / N, d = i % N;
         unsigned char *r = smem + G::oIc + (c * kMaxCars + d) * 16;
         // degradation per lap of tyre age: compound rate x driver factor, reference :319-322
         *reinterpret_cast<double *>(r) = P->comp_deg[c] * P->factor[d];
-        *reinterpret_cast<uint32_t *>(r + 8) = P->opt_laps[d * kCompStride + c];
-        *reinterpret_cast<uint32_t *>(r + 12) = 0u;
+        // pit word: threshold << 16, to be compared with (tyre age + 1) << 16 taken straight from pk (:454-465); its
+        // bit 0 = "the DNF draw always hits" (threshold 2^32, i.e. p >= 1), which a 32-bit threshold cannot say
+        const uint64_t t = P->t_dnf[d];
+        *reinterpret_cast<uint32_t *>(r + 8) = ((uint32_t)P->opt_laps[d * kCompStride + c] << 16) | (t > 0xFFFFFFFFull ? 1u : 0u);
+        *reinterpret_cast<uint32_t *>(r + 12) = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;      // reference :190-194
     }
     for (uint32_t c = tid; c < (uint32_t)kCompStride; c += B) {
         double *r = reinterpret_cast<double *>(smem + G::oComp + c * 16);
@@ -455,6 +468,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 {
     using G = RegGeo<N>;
     constexpr int B = G::B;
+    static_assert(MCGP_STEP_BATCH % 2 == 0, "a Philox block serves two consecutive places");
     const uint32_t tid4 = tid * 4u, tid8 = tid * 8u;
     const int L = P->total_laps;
     const int track = P->track;
@@ -464,20 +478,17 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     double *t_grid = reinterpret_cast<double *>(smem + G::oGrid);          // [slot][driver]
 
     // per-lane rows by ABSOLUTE LDS address (race_isa.hip.h): a compile-time row is an immediate offset ...
-    auto z_row = [&](int d) -> uint32_t { return G::oZ + (uint32_t)d * (B * 4) + tid4; };
-    auto l_row = [&](int d) -> uint32_t { return G::oLast + (uint32_t)(d % last_rows_reg(N)) * (B * 8) + tid8; };
-    // ... and the row of the driver held in a pk word is one and-or (B = 256); the f64 row sits at twice that offset
-    auto row4 = [&](uint32_t p) -> uint32_t {
-        if constexpr (B == 256) return (p & k3IdMask) | tid4;
-        else if constexpr (B == 512) return ((p & k3IdMask) << 1) | tid4;
-        else if constexpr (B == 128) return ((p & k3IdMask) >> 1) | tid4;
-        else if constexpr (B == 64) return ((p & k3IdMask) >> 2) | tid4;
-        else return ((p >> k3IdShift) & 31u) * (uint32_t)(B * 4) + tid4;
-    };
+    auto w_row = [&](int r) -> uint32_t { return G::oW + (uint32_t)r * (B * 4) + tid4; };
+    auto l_row = [&](int d) -> uint32_t { return G::oLast + (uint32_t)d * (B * 8) + tid8; };
+    // ... the LAST row of the driver held in a pk word is one bit-field extract and one multiply-add (the base
+    // G::oLast goes into the DS immediate) ...
+    auto last_of = [&](uint32_t p) -> uint32_t { return ((p >> k3IdShift) & 31u) * (uint32_t)(B * 8) + tid8; };
+    // ... and the byte of grid slot `pos` in the W plane (the sampled grid, before lap 1)
+    auto grid_byte = [&](int pos) -> uint32_t { return G::oW + (uint32_t)(pos >> 2) * (B * 4) + tid4 + (uint32_t)(pos & 3); };
     auto norm_row = [&](uint32_t row) -> float4 { return lds_ld_float4(G::oNorm + row * 16u); };
 
     const double pit_loss = P->pit_loss;
-    const double overtake_delta = P->overtake_delta;
+    const double od31 = P->overtake_delta * 2147483648.0;      // overtake_delta x 2^31 (exact), see reg_load_tables
     const double dirty_thr = P->dirty_thr;
     const double dirty_pen = P->dirty_pen;
     const float kNaN = __uint_as_float(0x7fc00000u);
@@ -486,28 +497,21 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 
     // Everything the lap step of one slot reads from LDS.
     struct SlotIn {
-        float z;
-        uint32_t opt;
+        uint32_t pitw;          // pit threshold << 16 | "the DNF draw always hits"
+        uint32_t tdnf;          // DNF draw threshold (32 bits)
         double last, var, base, eff, cdelta, drs;
-        uint32_t a4;            // byte offset of the driver's Z row (the LAST row is at twice that)
-        uint32_t la;
+        uint32_t la;            // byte offset of the driver's LAST row
     };
     auto load_slot = [&](uint32_t p) -> SlotIn {
         SlotIn r;
-        r.a4 = row4(p);
-        r.z = lds_ld<float>(G::oZ + r.a4);
-#ifdef MCGP_HACK_LDS3
-        r.la = ((p >> k3IdShift) & 7u) * (uint32_t)(B * 8) + tid8;
-#else
-        r.la = r.a4 << 1;
-#endif
+        r.la = last_of(p);
         r.last = lds_ld<double>(G::oLast + r.la);
         const uint32_t id16 = (p >> 6) & 0x1F0u;                                  // 16 x driver
         const uint32_t ic = id16 + ((p & k3CompMask) << 2);                       // 16 x (32 compound + driver)
         const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);
         r.var = vb.x;
         r.base = vb.y;
-        lds_ld_f64_u32(G::oIc + ic, r.eff, r.opt);
+        lds_ld_f64_u32x2(G::oIc + ic, r.eff, r.pitw, r.tdnf);
         r.cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));                 // 16 x compound
         r.drs = lds_ld<double>(G::oDrs + (p & k3Drs));                            // 0.0 or drs_delta
         return r;
@@ -583,14 +587,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     if (sel >= (uint32_t)N) sel = 31u - (uint32_t)__clz((int)remaining);   // unreachable: cdf[-1] == 1 > u
                 }
                 if ((remaining >> sel) & 1u) { remaining &= ~(1u << sel); --n_remaining; }
-                lds_st<uint32_t>(z_row(pos), sel);
+                lds_st<uint8_t>(grid_byte(pos), (uint8_t)sel);
             }
         }
 
         // ================= _initialize_cars, reference :244-273 (slot i = grid position i) =================
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const uint32_t id = lds_ld<uint32_t>(z_row(i));
+            const uint32_t id = lds_ld<uint8_t>(grid_byte(i));
             uint32_t comp, age;
             if (track == 2) { comp = 4u; age = 0u; }
             else if (track == 1) { comp = 3u; age = 0u; }
@@ -601,21 +605,26 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         }
 
         // ================= _simulate_lap_1, reference :275-311 =================
-        // draws by driver (wave-uniform thresholds): Z = lap-noise deviate or NaN (retired), LAST = start deviate
+        // draws by DRIVER (wave-uniform thresholds), staged in the LAST rows, which lap 1 does not use otherwise (Q3):
+        // low word = lap-noise deviate or NaN (retired), high word = start deviate
 #pragma unroll 1
         for (int d = 0; d < N; ++d) {
             uint32_t w0, w1, w2, w3;
             philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
             const bool out = (uint64_t)w0 < P->t_dnf1[d];
-            lds_st<float>(z_row(d), out ? kNaN : normal_from_u32_rows(w1, norm_row));
-            lds_st<double>(l_row(d), (double)normal_from_u32_rows(w2, norm_row));
+            lds_st<float>(l_row(d), out ? kNaN : normal_from_u32_rows(w1, norm_row));
+            lds_st<float>(l_row(d) + 4u, normal_from_u32_rows(w2, norm_row));
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const uint32_t p = pk[i];
-            const SlotIn s = load_slot(p);
-            const float z = s.z;
-            const double zs = s.last;
+            const uint32_t la = last_of(p);
+            const float z = lds_ld<float>(G::oLast + la);
+            const double zs = (double)lds_ld<float>(G::oLast + la + 4u);
+            const uint32_t id16 = (p >> 6) & 0x1F0u;
+            const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);                        // {variance, base pace}
+            const double eff = lds_ld<double>(G::oIc + id16 + ((p & k3CompMask) << 2));
+            const double cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));
             if (z != z) {
                 pk[i] = (p & ~k3AgeMask) | k3Dnf | (1u << k3AgeShift);
                 // The reference leaves a lap-1 retirement at cumulative_time 0.0, so several of them tie; ties sort
@@ -628,10 +637,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 cum[i] = -(double)(i + 1) * 0x1p-1000;
             } else {
                 const uint32_t age = (p >> k3AgeShift) & 0x7FFu;
-                const double tire = (double)age * s.eff;
+                const double tire = (double)age * eff;
                 const double fuel_effect = (110.0 - 110.0) * 0.03;
-                const double noise = 0.0 + s.var * (double)z;
-                const double base_lap = s.base + tire - fuel_effect + s.cdelta - 0.0 + noise;
+                const double noise = 0.0 + vb.x * (double)z;
+                const double base_lap = vb.y + tire - fuel_effect + cdelta - 0.0 + noise;
                 double pf = 0.5 + (double)(i + 1) * 0.1;
                 if (!(pf < 1.5)) pf = 1.5;
                 double sd = 0.0 + pf * zs;
@@ -650,13 +659,20 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll 1
         for (int lap = 2; lap <= ((MCGP_SKIP & 8) ? 1 : L); ++lap) {
             const int remaining_laps = L - lap;
+            // The simulation id as this lap sees it: opaque to the optimiser, so that it does not lift the lap-
+            // invariant part of every Philox block of the loop body (round 1 depends on the id and the block's
+            // constant address only) out of the lap loop -- a dozen blocks x 3 registers held across the whole race.
+            // Within the lap the shared part is still computed once.
+            uint32_t c0l = c0, c1l = c1;
+            pin(c0l);
+            pin(c1l);
             // ---- race-interrupting events, :168-176 ----
             {
                 uint32_t e0, e1, e2, e3;
-                philox4x32_10(c0, c1, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, e0, e1, e2, e3);
+                philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, e0, e1, e2, e3);
                 if (MCGP_DUP & 16) {
                     uint32_t f0, f1, f2, f3;
-                    philox4x32_10(c0 ^ e0, c1, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, f0, f1, f2, f3);
+                    philox4x32_10(c0l ^ e0, c1l, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, f0, f1, f2, f3);
                     if ((f0 | f1 | f2 | f3) == 0u) e0 = f0;     // never true in practice; keeps the block alive
                 }
                 const bool red = (uint64_t)e0 < t_red;
@@ -701,42 +717,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     }
                     drs_disabled_until = lap + (vsc ? 1 : 2);
                     // Re-spacing keeps the running cars' relative order (the only order the lap loop below
-                    // needs; the full order is rebuilt after it).  x0.8 is monotone but may round two gaps
-                    // together, and equal times must fall back to grid order: re-sort only then.
+                    // needs; the full order is rebuilt after it), and the FIELD ORDER that addresses this lap's
+                    // draws stays what the last lap left.  x0.8 is monotone but may round two gaps together, and
+                    // equal times must fall back to grid order: re-sort only then (the oracle does the same).
                     if (tie) transposition_sort<N>(cum, pk);
-                }
-            }
-
-            // ---- this lap's draws, by driver pair: one Philox block = (dnf, noise) x 2 ----
-            // MCGP_PREPASS_BLOCKS blocks per iteration: their Philox chains interleave, and the table
-            // look-ups of the inverse-normal transform go out as one batch.
-#pragma unroll 1
-            for (int rep = 0; rep < ((MCGP_DUP & 2) ? 2 : 1); ++rep)
-#pragma unroll 1
-            for (int b0 = 0; b0 < (N + 1) / 2; b0 += MCGP_PREPASS_BLOCKS) {
-                uint32_t w[MCGP_PREPASS_BLOCKS][4];
-#pragma unroll
-                for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
-                    w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0u;
-                    if (b0 + j < (N + 1) / 2)
-                        philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | (uint32_t)(b0 + j), seed_lo, seed_hi,
-                                      w[j][0], w[j][1], w[j][2], w[j][3]);
-                }
-                float z[MCGP_PREPASS_BLOCKS][2];
-                unsigned long long q[MCGP_PREPASS_BLOCKS][2];
-#pragma unroll
-                for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
-                    const int d0 = 2 * (b0 + j), d1 = d0 + 1;
-                    z[j][0] = normal_from_u32_rows(w[j][1], norm_row);
-                    z[j][1] = normal_from_u32_rows(w[j][3], norm_row);
-                    q[j][0] = P->t_dnf[d0 < N ? d0 : 0];              // wave-uniform: scalar loads
-                    q[j][1] = P->t_dnf[d1 < N ? d1 : 0];
-                }
-#pragma unroll
-                for (int j = 0; j < MCGP_PREPASS_BLOCKS; ++j) {
-                    const int d0 = 2 * (b0 + j), d1 = d0 + 1;
-                    if (d0 < N) lds_st<float>(z_row(d0), ((uint64_t)w[j][0] < q[j][0]) ? kNaN : z[j][0]);
-                    if (d1 < N) lds_st<float>(z_row(d1), ((uint64_t)w[j][2] < q[j][1]) ? kNaN : z[j][1]);
                 }
             }
 
@@ -745,6 +729,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             // LDS gathers of MCGP_STEP_BATCH slots stay in flight together (nothing can be sunk into a branch) and
             // the wave does not pay exec-mask bookkeeping per car.  What a retired car "computes" is discarded:
             // +0.0 on its time, its pk kept, and a LAST value nobody reads (only running cars feed `carry`).
+            // The draws of places 2j and 2j+1 are the four words of ONE Philox block, computed here between the
+            // gathers and their use (it covers their latency) and consumed from registers.
             {
                 double fuel = 110.0 - 1.5 * (double)(lap - 1);
                 if (!(fuel > 0)) fuel = 0.0;
@@ -755,33 +741,50 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const uint32_t retire_bits = k3Dnf | ((uint32_t)lap << k3AgeShift);
                 double carry = 0.0;
 #pragma unroll
-                for (int i0 = 0; i0 < N; i0 += MCGP_STEP_BATCH) {
+                for (int i0 = 0; i0 < ((MCGP_SKIP & 64) ? 0 : N); i0 += MCGP_STEP_BATCH) {
+                    MCGP_SCHED_FENCE();          // one batch at a time: gathers hoisted from later batches cost registers
                     SlotIn in[MCGP_STEP_BATCH];
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j)
                         if (i0 + j < N) in[j] = load_slot(pk[i0 + j]);
+                    uint32_t w[MCGP_STEP_BATCH / 2][4];
+#pragma unroll
+                    for (int b = 0; b < MCGP_STEP_BATCH / 2; ++b) {
+                        w[b][0] = w[b][1] = w[b][2] = w[b][3] = 0u;
+                        if (i0 + 2 * b < N)
+                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | (uint32_t)((i0 >> 1) + b), seed_lo, seed_hi,
+                                          w[b][0], w[b][1], w[b][2], w[b][3]);
+                    }
+                    float z[MCGP_STEP_BATCH];
+#pragma unroll
+                    for (int j = 0; j < MCGP_STEP_BATCH; ++j)
+                        z[j] = (i0 + j < N) ? normal_from_u32_rows(w[j >> 1][2 * (j & 1) + 1], norm_row) : 0.0f;
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
                         const int i = i0 + j;
                         if (i >= N) continue;
                         const SlotIn &s = in[j];
                         const uint32_t p = pk[i];
+                        const uint32_t wd = w[j >> 1][2 * (j & 1)];
                         const bool active = !(p & k3Dnf);                   // running at the start of the lap
-                        const bool retire = active && (s.z != s.z);         // this lap's DNF draw hit   :194-197
-                        const bool run = active && !(s.z != s.z);
+                        // this lap's DNF draw (:194-197): u < p  <=>  word < ceil(p 2^32), or p >= 1
+                        const bool dnf_hit = lt_u64(wd, s.tdnf, s.pitw & 1u);
+                        const bool retire = active && dnf_hit;
+                        const bool run = active && !dnf_hit;
                         const double ahead_last = carry;                    // last lap of the running car ahead  :179-183
                         carry = active ? s.last : carry;
-                        const uint32_t age = (p >> k3AgeShift) & 0x7FFu;
-                        const double tire = (double)age * s.eff;                                   // :319-322
+                        const uint32_t agef = p & k3AgeMask;
+                        const double tire = (double)(agef >> k3AgeShift) * s.eff;                   // :319-322
                         const double drs_gain = s.drs;                                              // :327
-                        const double noise = 0.0 + s.var * (double)s.z;                             // :330
+                        const double noise = 0.0 + s.var * (double)z[j];                            // :330
                         const double clean = s.base + tire - fuel_effect + s.cdelta - drs_gain + noise;   // :332
                         const double dirty_time = clean + dirty_pen;                                // :213
                         const double held = ahead_last > dirty_time ? ahead_last : dirty_time;       // :215
                         const bool in_dirty = (p & k3Dirty) && ahead_last > 0;                      // :209-212
                         const double lap_time = in_dirty ? held : clean;
-                        // pit stop (:450-492): compound and used-set from the per-lap rule tables
-                        const bool pit = run && pit_window && (int)(age + 1u) > (int)s.opt;
+                        // pit stop (:450-492): (tyre age + 1) << 16 against the pit word; compound and used-set from
+                        // the per-lap rule tables
+                        const bool pit = run && pit_window && (agef + (1u << k3AgeShift)) > s.pitw;
                         const uint32_t u3 = (p & k3UsedMask) * 3u;
                         const uint32_t newc = (lut_comp >> u3) & 7u, newu = (lut_used >> u3) & 7u;
                         const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | (newc << k3CompShift) | newu;
@@ -793,26 +796,30 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         // x + 0.0 == x for the finite, non-negative times here: cars that do not run keep their time
                         const double t = cum[i] + (run ? lap_time : 0.0);
                         cum[i] = t + (pit ? pit_loss : 0.0);                                        // :464
+                        pin(cum[i]);             // done HERE: not sunk, with its masks and lap time, to where it is used
                         lds_st<double>(G::oLast + s.la, lap_time);                                  // :219
                     }
                 }
             }
 
             // ---- _simulate_overtakes, :496-536 ----
-            network_sort<N>(cum, pk);
+            if (!(MCGP_SKIP & 16)) network_sort<N>(cum, pk);
             if (MCGP_DUP & 1) network_sort<N>(cum, pk);
 #pragma unroll 1
             for (int pass = 0; pass < ((MCGP_SKIP & 1) ? 0 : 3); ++pass) {
                 // ---- overtakes: pace deltas and candidates ----
-                // pace of every slot (:514-515) and the pace delta of every adjacent pair.  The per-driver
-                // constants are gathered half a field at a time (one s_waitcnt per half, not per slot).
-                double delta[N];
+                // pace of every slot (:514-515), the pace delta of every adjacent pair, and what an attempt needs to
+                // succeed.  Everything is scaled by 2^31 (tables, reg_load_tables): u < min(0.5, delta / 2) for the
+                // uniform u = w 2^-32 is  w < 2^31  and  w < delta 2^31,  i.e.  w < thr = min(ceil(delta 2^31), 2^31)
+                // -- one integer per pair instead of a binary64 delta kept across the draw-word generation.
+                uint32_t thr[N];
                 uint32_t cand = 0u;
                 {
-                    constexpr int H = (N + 1) / 2;
+                    constexpr int H = MCGP_PACE_BATCH;
                     double pace_prev = 0.0;
 #pragma unroll
                     for (int h = 0; h < N; h += H) {
+                        MCGP_SCHED_FENCE();
                         double pb[H], pd[H], pa[H];
 #pragma unroll
                         for (int j = 0; j < H; ++j) {
@@ -821,7 +828,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                 const f64x2 bd = lds_ld_f64x2(G::oDrvB + id16);
                                 pb[j] = bd.x;
                                 pd[j] = bd.y;
-                                pa[j] = lds_ld<double>(G::oDrs + (pk[h + j] & k3Drs));
+                                pa[j] = lds_ld<double>(G::oDrsB + (pk[h + j] & k3Drs));
                             }
                         }
 #pragma unroll
@@ -831,46 +838,86 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                 // a retired car's pace is NaN (table): its two pairs compare false below (:511)
                                 const double pace = pb[j] + (double)((pk[i] >> k3AgeShift) & 0x7FFu) * pd[j];
                                 if (i > 0) {
-                                    const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520
-                                    delta[i] = dl;
-                                    if (dl > overtake_delta) cand |= 1u << i;                       // :522
+                                    const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520 (x 2^31)
+                                    const bool c = dl > od31;                                       // :522
+                                    cand |= c ? (1u << i) : 0u;
+                                    const uint32_t t = min_u32(cvt_u32_f64_sat(ceil_f64(dl)), 0x80000000u);
+                                    thr[i] = c ? t : 0u;                                            // :523-524
                                 }
                                 pace_prev = pace;
                             }
                         }
                     }
+                    thr[0] = 0u;
                 }
                 MCGP_STAT(0 + pass, cand != 0u);
                 if (cand == 0u) break;
                 // ---- overtakes: draw words ----
-                // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4
+                // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4.  Up to 8 attempts per lane
+                // -- all but a few wave-passes in a thousand -- go through the W plane in one go: ow[i] = the word of the
+                // attempt at pair i.  A wave with a busier lane takes the general path, 8 attempts at a time, and leaves
+                // its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
                 const int n_cand = __popc(cand);
-#pragma unroll 1
-                for (int b = 0; 4 * b < n_cand; ++b) {
-                    uint32_t o0, o1, o2, o3;
-                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + b), seed_lo, seed_hi,
-                                  o0, o1, o2, o3);
-                    lds_st<uint32_t>(z_row(4 * b + 0), o0);
-                    lds_st<uint32_t>(z_row(4 * b + 1), o1);
-                    lds_st<uint32_t>(z_row(4 * b + 2), o2);
-                    lds_st<uint32_t>(z_row(4 * b + 3), o3);
-                }
-                // ---- overtakes: which attempts succeed ----
-                // which attempts succeed (:523-524) does not depend on the times: all draw words are
-                // fetched in one batch and compared before the sequential write-back chain
                 uint32_t ow[N];
+                ow[0] = 0u;
+                if (__builtin_expect(MCGP_ANY(n_cand > kWordRows), 0)) {
+                    uint32_t hits = 0u, rest = cand;
+#pragma unroll 1
+                    for (int chunk = 0; rest != 0u; ++chunk) {
+                        uint32_t m = rest;                                  // `rest` without its 8 lowest set bits
+#pragma unroll 1
+                        for (int k = 0; k < kWordRows && m != 0u; ++k) m &= m - 1u;
+                        const uint32_t cur = rest & ~m;                     // attempts 8 chunk .. 8 chunk + 7
+#pragma unroll 1
+                        for (int b = 0; b < 2; ++b) {
+                            uint32_t o0, o1, o2, o3;
+                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 2 * chunk + b), seed_lo,
+                                          seed_hi, o0, o1, o2, o3);
+                            lds_st<uint32_t>(w_row(4 * b + 0), o0);
+                            lds_st<uint32_t>(w_row(4 * b + 1), o1);
+                            lds_st<uint32_t>(w_row(4 * b + 2), o2);
+                            lds_st<uint32_t>(w_row(4 * b + 3), o3);
+                        }
+                        uint32_t h = 0u;
 #pragma unroll
-                for (int i = 1; i < N; ++i)
-                    ow[i] = lds_ld<uint32_t>(G::oZ + (uint32_t)__popc(cand & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4);
+                        for (int i = 1; i < N; ++i) {
+                            // (a pair outside `cur` reads some other word, or just past the plane: masked out below)
+                            const uint32_t word = lds_ld<uint32_t>(G::oW + (uint32_t)__popc(cur & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4);
+                            h |= word < thr[i] ? (1u << i) : 0u;
+                        }
+                        hits |= h & cur;
+                        rest = m;
+                    }
+#pragma unroll
+                    for (int i = 1; i < N; ++i) {
+                        thr[i] = (hits >> i) & 1u;
+                        ow[i] = 0u;
+                    }
+                } else {
+                    uint32_t o0, o1, o2, o3;
+                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass), seed_lo, seed_hi, o0, o1, o2, o3);
+                    lds_st<uint32_t>(w_row(0), o0);
+                    lds_st<uint32_t>(w_row(1), o1);
+                    lds_st<uint32_t>(w_row(2), o2);
+                    lds_st<uint32_t>(w_row(3), o3);
+                    if (n_cand > 4) {
+                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 1), seed_lo, seed_hi, o0, o1, o2, o3);
+                        lds_st<uint32_t>(w_row(4), o0);
+                        lds_st<uint32_t>(w_row(5), o1);
+                        lds_st<uint32_t>(w_row(6), o2);
+                        lds_st<uint32_t>(w_row(7), o3);
+                    }
+#pragma unroll
+                    for (int i = 1; i < N; ++i)
+                        ow[i] = lds_ld<uint32_t>(G::oW + (uint32_t)__popc(cand & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4);
+                }
                 // ---- overtakes: success test and write-back chain ----
                 // :523-531 in sorted order, each pair seeing the previous pair's mutation (Q15).  Branch-free: the
                 // new times of a pair are computed for every slot and committed by selects under the success mask.
                 bool any_succ = false;
 #pragma unroll
                 for (int i = 1; i < N; ++i) {
-                    // u < min(0.5, delta / 2)  <=>  w < 2^31  and  w * 2^-31 < delta   (u = w * 2^-32, exact scalings)
-                    const bool hit = ((cand >> i) & 1u) && ow[i] < 0x80000000u &&
-                                     (double)ow[i] * (1.0 / 2147483648.0) < delta[i];
+                    const bool hit = ow[i] < thr[i];
                     const double nb = max_f64(cum[i - 1] - 0.1, 0.1);          // max(0.1, ahead - 0.1), :528
                     const double na = nb + 0.3;                                // :530
                     cum[i] = hit ? nb : cum[i];
@@ -879,46 +926,47 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 }
                 MCGP_STAT(4 + pass, any_succ);
                 MCGP_STAT(8, __popc(cand));
+                MCGP_TRACE_PASS(local, lap, pass, __popc(cand));
                 if (!any_succ) break;
                 // ---- overtakes: re-sort ----
                 resort_after_overtakes<N>(cum, pk);     // sorted again for the next pass / _update_positions
                 if (MCGP_DUP & 8) resort_after_overtakes<N>(cum, pk);
             }
             // ---- _update_positions, :227-228 ----
-            update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
+            if (!(MCGP_SKIP & 32)) update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
             if (MCGP_DUP & 4) update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
         }
 
         // ================= classification, reference :230-242 =================
-        // rows to LDS (cum -> LAST rows, pk -> W rows), insertion sort with the classification
-        // order: running cars by time, then retired cars by (lap, time) descending, stable.
+        // Running cars by time, then retired cars by (lap, time) descending, stable.  The field is in (time, grid
+        // slot) order, so all of that is one integer per car: a running car's key is its rank; a retired car's is
+        //     1 << 26 | (2047 - lap) << 15 | (31 - g) << 10 | grid slot << 5,     g = index of its time among the
+        // distinct times in ascending order (equal times share g and fall back to grid order, the reference's
+        // stable tie; lap-1 retirements carry distinct negative times, see lap 1).  The driver rides in the low 5 bits.
+        {
+            uint32_t g = 0u;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            lds_st<double>(l_row(i), cum[i]);
-            lds_st<uint32_t>(z_row(i), pk[i]);
+            for (int i = 0; i < N; ++i) {
+                if (i > 0) g += cum[i] != cum[i - 1] ? 1u : 0u;
+                const uint32_t p = pk[i];
+                const uint32_t id = (p >> k3IdShift) & 31u;
+                const uint32_t lapf = (p >> k3AgeShift) & 0x7FFu;
+                const uint32_t key_dnf = (1u << 26) | ((2047u - lapf) << 15) | ((31u - g) << 10) | ((p >> k3GposShift) << 5) | id;
+                const uint32_t key_run = ((uint32_t)i << 5) | id;
+                lds_st<uint32_t>(l_row(i), (p & k3Dnf) ? key_dnf : key_run);
+            }
         }
 #pragma unroll 1
-        for (int i = 1; i < N; ++i) {
-            const uint32_t pkx = lds_ld<uint32_t>(z_row(i));
-            const double kx = lds_ld<double>(l_row(i));
+        for (int i = 1; i < N; ++i) {                                   // insertion sort of the keys (LAST rows, dead now)
+            const uint32_t kx = lds_ld<uint32_t>(l_row(i));
             int j = i;
             while (j > 0) {
-                const uint32_t pky = lds_ld<uint32_t>(z_row(j - 1));
-                const double ky = lds_ld<double>(l_row(j - 1));
-                bool y_after_x;
-                if (!(pky & k3Dnf)) y_after_x = false;            // runners are already in order and ahead of retirees
-                else if (!(pkx & k3Dnf)) y_after_x = true;
-                else {
-                    const uint32_t ly = pky & k3AgeMask, lx = pkx & k3AgeMask;
-                    y_after_x = ly < lx || (ly == lx && (ky < kx || (ky == kx && pky > pkx)));
-                }
-                if (!y_after_x) break;
-                lds_st<uint32_t>(z_row(j), pky);
-                lds_st<double>(l_row(j), ky);
+                const uint32_t ky = lds_ld<uint32_t>(l_row(j - 1));
+                if (!(ky > kx)) break;
+                lds_st<uint32_t>(l_row(j), ky);
                 --j;
             }
-            lds_st<uint32_t>(z_row(j), pkx);
-            lds_st<double>(l_row(j), kx);
+            lds_st<uint32_t>(l_row(j), kx);
         }
         // finishing order: N bytes per simulation, contiguous per lane.  Four positions are packed into one dword
         // store when the lane's N-byte record is dword aligned (N % 4 == 0 and an aligned buffer): N / 4 stores per
@@ -927,7 +975,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         uint32_t packed = 0u;
 #pragma unroll 1
         for (int p = 0; p < N; ++p) {
-            const uint32_t d = (lds_ld<uint32_t>(z_row(p)) >> k3IdShift) & 31u;
+            const uint32_t d = lds_ld<uint32_t>(l_row(p)) & 31u;
             atomicAdd(&s_hist[d * N + p], 1u);                       // reference :93-94
             if (orders) {
                 if (dword_orders) {

@@ -266,8 +266,13 @@ double orc_phi_inverse_tail(uint64_t q53, float z_start) { return phi_inverse_ta
 /*   GRID  (lap 0)  index = slot >> 2, word = slot & 3                         */
 /*   EVENT (lap)    words: red flag, safety car, VSC, VSC tyre draw            */
 /*   CAR   (lap 1)  index = driver; words: DNF, lap noise, start delta          */
-/*   CAR   (lap>=2) index = driver >> 1 (one block serves two drivers);        */
-/*                   words 2 (driver & 1) + {0: DNF, 1: lap noise}              */
+/*   CAR   (lap>=2) index = place >> 1 (one block serves two cars), words       */
+/*                   2 (place & 1) + {0: DNF, 1: lap noise}, where `place` is   */
+/*                   the car's place in the FIELD ORDER the lap starts with:    */
+/*                   all cars, retired ones included, in the time order of the  */
+/*                   end of the previous lap (stable, i.e. grid order on equal  */
+/*                   times) -- re-sorted only if a VSC has just rounded two     */
+/*                   running cars onto the same time (field_order_* below)      */
 /*   OVT   (lap)    the k-th overtake ATTEMPT of pass p (k counted along the   */
 /*                   pass's sorted order) reads word k & 3 of index 8p + k / 4  */
 /* ------------------------------------------------------------------------- */
@@ -325,11 +330,12 @@ static double draw_event(rng_t *r, int lap, int which)
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :168,171,174,392 */
     return philox_uniform(r, (uint32_t)lap, PURPOSE_EVENT, 0, which);
 }
-static double draw_dnf(rng_t *r, int lap, int driver)
+/* `who`: the driver index on lap 1, the car's place in the field order from lap 2 on (see above) */
+static double draw_dnf(rng_t *r, int lap, int who)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :194,287 */
-    if (lap == 1) return philox_uniform(r, 1u, PURPOSE_CAR, (uint32_t)driver, 0);
-    return philox_uniform(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1));
+    if (lap == 1) return philox_uniform(r, 1u, PURPOSE_CAR, (uint32_t)who, 0);
+    return philox_uniform(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)who >> 1, 2 * (who & 1));
 }
 static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
 {
@@ -337,11 +343,11 @@ static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
     return philox_uniform(r, (uint32_t)lap, PURPOSE_OVT, (uint32_t)(8 * pass + (attempt >> 2)), attempt & 3);
 }
 /* np.random.normal(0, scale) */
-static double draw_lap_noise(rng_t *r, int lap, int driver, double scale)
+static double draw_lap_noise(rng_t *r, int lap, int who, double scale)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return orc_mt_np_normal(r->mt, 0.0, scale);   /* :330 */
-    const double z = lap == 1 ? philox_normal(r, 1u, PURPOSE_CAR, (uint32_t)driver, 1)
-                              : philox_normal(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)driver >> 1, 2 * (driver & 1) + 1);
+    const double z = lap == 1 ? philox_normal(r, 1u, PURPOSE_CAR, (uint32_t)who, 1)
+                              : philox_normal(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)who >> 1, 2 * (who & 1) + 1);
     return 0.0 + scale * z;
 }
 static double draw_start_delta(rng_t *r, int driver, double scale)
@@ -447,7 +453,7 @@ static void initialize_cars(const sim_t *s, const uint8_t *grid, car_t *cars)
 }
 
 /* _calculate_lap_time, reference :313-332 */
-static double calculate_lap_time(const sim_t *s, const car_t *car, int lap)
+static double calculate_lap_time(const sim_t *s, const car_t *car, int lap, int who)
 {
     const orc_config *cfg = s->cfg;
     const double base = s->drv->base_pace[car->driver];
@@ -460,7 +466,7 @@ static double calculate_lap_time(const sim_t *s, const car_t *car, int lap)
     const double fuel_effect = (110.0 - car->fuel_load) * 0.03;
     const double compound_delta = cfg->comp_pace_delta[car->tire_compound];
     const double drs_gain = car->drs_enabled ? cfg->drs_delta : 0.0;
-    const double noise = draw_lap_noise(s->rng, lap, car->driver, variance);
+    const double noise = draw_lap_noise(s->rng, lap, who, variance);
     return base + tire_effect - fuel_effect + compound_delta - drs_gain + noise;
 }
 
@@ -493,7 +499,7 @@ static void simulate_lap_1(const sim_t *s, car_t *cars)
             car->lap = 1;
             continue;
         }
-        const double base_lap_time = calculate_lap_time(s, car, 1);
+        const double base_lap_time = calculate_lap_time(s, car, 1, car->driver);
         double position_factor = 0.5 + (double)car->position * 0.1;
         if (!(position_factor < 1.5)) position_factor = 1.5;             /* min(1.5, x) */
         double start_delta = draw_start_delta(s->rng, car->driver, position_factor);
@@ -670,6 +676,26 @@ static void record_trace(const sim_t *s, const car_t *cars, const orc_trace *tr,
     }
 }
 
+/* Field order of the counter-based back-ends (not part of the reference, which draws from sequential streams):
+ * place[car] = the car's rank among ALL cars by cumulative time, stable (grid order on equal times) -- the order
+ * the overtake step's sorted(cars) at reference :506 would produce. */
+static void field_order_sort(const car_t *cars, int n, int *place)
+{
+    int idx[MCGP_ORACLE_MAX_CARS];
+    for (int i = 0; i < n; i++) idx[i] = i;
+    stable_sort_by_time(cars, idx, n);
+    for (int i = 0; i < n; i++) place[idx[i]] = i;
+}
+/* two running cars on exactly the same time? (after a VSC's x0.8 the only way the running order can become ambiguous) */
+static int running_cars_tie(const car_t *cars, int n)
+{
+    int idx[MCGP_ORACLE_MAX_CARS];
+    const int m = active_sorted(cars, n, idx);
+    for (int i = 1; i < m; i++)
+        if (cars[idx[i]].cumulative_time == cars[idx[i - 1]].cumulative_time) return 1;
+    return 0;
+}
+
 /* simulate_race, reference :147-242.  order_out[p] = driver index classified p-th. */
 static void simulate_race(const sim_t *s, const uint8_t *grid, uint8_t *order_out,
                           const orc_trace *tr, int64_t sim_index)
@@ -681,6 +707,8 @@ static void simulate_race(const sim_t *s, const uint8_t *grid, uint8_t *order_ou
     simulate_lap_1(s, cars);
     record_trace(s, cars, tr, sim_index, 1);
     int drs_disabled_until = 0;
+    int place[MCGP_ORACLE_MAX_CARS];                    /* field order (Philox draw addresses only) */
+    field_order_sort(cars, n, place);
 
     for (int lap = 2; lap <= cfg->total_laps; lap++) {
         /* :168-176, short-circuit chain (Q8) */
@@ -693,6 +721,7 @@ static void simulate_race(const sim_t *s, const uint8_t *grid, uint8_t *order_ou
         } else if (draw_event(s->rng, lap, 2) < cfg->vsc_probability) {
             handle_vsc(s, cars, lap);
             drs_disabled_until = lap + 1;
+            if (running_cars_tie(cars, n)) field_order_sort(cars, n, place);
         }
 
         /* :179-183 car ahead's last lap, by car (grid index) */
@@ -706,12 +735,12 @@ static void simulate_race(const sim_t *s, const uint8_t *grid, uint8_t *order_ou
         for (int i = 0; i < n; i++) {
             car_t *car = &cars[i];
             if (car->dnf) continue;
-            if (draw_dnf(s->rng, lap, car->driver) < s->drv->lap_dnf[car->driver]) {
+            if (draw_dnf(s->rng, lap, place[i]) < s->drv->lap_dnf[car->driver]) {
                 car->dnf = 1;
                 car->lap = lap;
                 continue;
             }
-            const double clean_air_time = calculate_lap_time(s, car, lap);
+            const double clean_air_time = calculate_lap_time(s, car, lap, place[i]);
             double lap_time = clean_air_time;
             if (car->time_behind_leader > 0) {
                 const double car_ahead_lap = car_ahead_time[i];
@@ -730,6 +759,7 @@ static void simulate_race(const sim_t *s, const uint8_t *grid, uint8_t *order_ou
 
         handle_pit_stops(s, cars, lap);                                   /* :225 */
         simulate_overtakes(s, cars, lap);                                 /* :226 */
+        field_order_sort(cars, n, place);
         update_positions(s, cars, lap, lap <= drs_disabled_until);        /* :227-228 */
         record_trace(s, cars, tr, sim_index, lap);
     }

@@ -11,6 +11,18 @@ extern "C" unsigned long long emu_stat_sum[16], emu_stat_calls[16];
 unsigned long long emu_stat_sum[16], emu_stat_calls[16];
 #endif
 #define MCGP_STAT(what, value) (emu_stat_sum[(what)] += (unsigned long long)(value), emu_stat_calls[(what)] += 1)
+// per-(simulation, lap, pass) trace of the number of overtake candidates (tools only): emu_trace_buf[sim][lap][pass] = n + 1
+extern "C" unsigned char *emu_trace_buf;
+extern "C" unsigned long long emu_trace_sims, emu_trace_laps;
+#if !defined(EMU_PART) || EMU_PART == 0
+unsigned char *emu_trace_buf = nullptr;
+unsigned long long emu_trace_sims = 0, emu_trace_laps = 0;
+#endif
+#define MCGP_TRACE_PASS(sim, lap, pass, n_cand)                                                              \
+    do {                                                                                                     \
+        if (emu_trace_buf && (unsigned long long)(sim) < emu_trace_sims && (unsigned long long)(lap) < emu_trace_laps) \
+            emu_trace_buf[((unsigned long long)(sim) * emu_trace_laps + (lap)) * 3 + (pass)] = (unsigned char)((n_cand) + 1); \
+    } while (0)
 #include "race_isa_host.h"
 
 #include "../../monte_carlo_gp_amd/csrc/params_build.h"

@@ -75,12 +75,33 @@ struct f64x2 {
     double x, y;
 };
 inline f64x2 lds_ld_f64x2(uint32_t addr) { return lds_ld<f64x2>(addr); }
-inline void lds_ld_f64_u32(uint32_t addr, double &d, uint32_t &u)
+inline void lds_ld_f64_u32x2(uint32_t addr, double &d, uint32_t &u0, uint32_t &u1)
 {
     d = lds_ld<double>(addr);
-    u = lds_ld<uint32_t>(addr + 8);
+    u0 = lds_ld<uint32_t>(addr + 8);
+    u1 = lds_ld<uint32_t>(addr + 12);
 }
+// v_cvt_u32_f64: toward zero, saturating, NaN -> 0
+inline uint32_t cvt_u32_f64_sat(double x)
+{
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+inline void sched_fence() {}
+inline double ceil_f64(double x) { return std::ceil(x); }
+inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+inline bool lt_u64(uint32_t w, uint32_t lo, uint32_t hi) { return (uint64_t)w < (((uint64_t)hi << 32) | (uint64_t)lo); }
+// threads of the emulated block run one after another: "any lane" is this thread alone (both paths behind an
+// MCGP_ANY test compute the same results, so which one a thread takes does not matter); EMU_FORCE_ANY=1 sends every
+// thread down the "some lane needs it" path, which a single-thread view would otherwise reach only rarely
+#ifdef EMU_FORCE_ANY
+#define MCGP_ANY(pred) ((void)(pred), true)
+#else
+#define MCGP_ANY(pred) (pred)
+#endif
 inline void pin(uint32_t &) {}
+inline void pin(double &) {}
 inline float4 lds_ld_float4(uint32_t addr) { return lds_ld<float4>(addr); }
 inline uint32_t lds_base_of(const void *p) { return (uint32_t)((const unsigned char *)p - smem); }
 }  // namespace mcgp
