@@ -239,11 +239,13 @@ MCGP_REG_SIZES(X)
 
 namespace {
 
-KernelFn select_kernel(uint32_t n, bool *is_reg)
+KernelFn select_kernel(const mcgp::KParams &kp, bool *is_reg)
 {
     *is_reg = false;
+    const uint32_t n = (uint32_t)kp.n;
     const char *force = std::getenv("MCGP_FORCE_GENERIC");
     if (force && force[0] == '1') return &mcgp::race_kernel;
+    if (!mcgp::reg_kernel_serves(kp)) return &mcgp::race_kernel;      // a DNF probability >= 1: 33-bit threshold
     switch (n) {
 #define X(N_) case N_: *is_reg = true; return &mcgp::race_kernel_reg<N_>;
         MCGP_REG_SIZES(X)
@@ -332,7 +334,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
 {
     if (n_sims == 0) return MCGP_OK;
     bool is_reg = false;
-    const KernelFn kernel = select_kernel((uint32_t)kp.n, &is_reg);
+    const KernelFn kernel = select_kernel(kp, &is_reg);
     DeviceCtx::Slot *sl = nullptr;
     if (!fe.on)           // a block whose matrix is written by the device front end is never shared
         for (auto &cand : c.slot)

@@ -309,6 +309,27 @@ __device__ __forceinline__ bool lt_u64(uint32_t w, uint32_t lo, uint32_t hi)
 }
 // scheduling fence: the compiler's instruction scheduler moves nothing across it
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// ---- cross-lane pieces of the cooperative event handler ----
+// LDS written by some lanes of the wave, read by others: program order is enough for the hardware (DS operations of
+// one wave execute in order); this keeps the compiler from moving LDS accesses across the hand-over.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane)       // lane: wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bpermute_f64(double x, int src_lane)   // src_lane: per lane
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 // true if the predicate holds in ANY lane of the wavefront (wave-uniform result)
 #define MCGP_ANY(pred) (__any((int)(pred)) != 0)
 // Keeps a value computed where it is written: the compiler may not sink its computation into one arm of a later

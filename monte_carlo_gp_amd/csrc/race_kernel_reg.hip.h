@@ -49,6 +49,11 @@
 #ifndef MCGP_TRACE_PASS
 #define MCGP_TRACE_PASS(sim, lap, pass, n_cand)
 #endif
+// Race-interrupting events handled by the wave with lane = car (1) or by every lane for itself (0: the same
+// results; kept for A/B runs and for the host debugging build, whose threads run one at a time).
+#ifndef MCGP_COOPERATIVE_EVENTS
+#define MCGP_COOPERATIVE_EVENTS 1
+#endif
 
 namespace mcgp {
 
@@ -392,6 +397,15 @@ __device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uin
 #define MCGP_PACE_BATCH 5          // slots whose pace gathers are in flight together in an overtake pass
 #endif
 
+// The register kernel keeps the per-lap DNF threshold in 32 bits: a driver who retires with CERTAINTY on every lap
+// (probability >= 1, threshold 2^32) does not fit and sends the whole problem to the generic kernel.
+__host__ __device__ inline bool reg_kernel_serves(const KParams &kp)
+{
+    for (int d = 0; d < kp.n; ++d)
+        if (kp.t_dnf[d] > 0xFFFFFFFFull) return false;
+    return true;
+}
+
 // Phase 1 of a block: fill the block-shared LDS tables (all threads, strided).
 template <int N>
 __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid)
@@ -429,11 +443,10 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         unsigned char *r = smem + G::oIc + (c * kMaxCars + d) * 16;
         // degradation per lap of tyre age: compound rate x driver factor, reference :319-322
         *reinterpret_cast<double *>(r) = P->comp_deg[c] * P->factor[d];
-        // pit word: threshold << 16, to be compared with (tyre age + 1) << 16 taken straight from pk (:454-465); its
-        // bit 0 = "the DNF draw always hits" (threshold 2^32, i.e. p >= 1), which a 32-bit threshold cannot say
-        const uint64_t t = P->t_dnf[d];
-        *reinterpret_cast<uint32_t *>(r + 8) = ((uint32_t)P->opt_laps[d * kCompStride + c] << 16) | (t > 0xFFFFFFFFull ? 1u : 0u);
-        *reinterpret_cast<uint32_t *>(r + 12) = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;      // reference :190-194
+        // pit word: threshold << 16, to be compared with (tyre age + 1) << 16 taken straight from pk (:454-465)
+        *reinterpret_cast<uint32_t *>(r + 8) = (uint32_t)P->opt_laps[d * kCompStride + c] << 16;
+        // DNF draw threshold, 32 bits: ceil(p 2^32) for p < 1 (reg_kernel_serves() keeps p >= 1 away from this kernel)
+        *reinterpret_cast<uint32_t *>(r + 12) = (uint32_t)P->t_dnf[d];                              // reference :190-194
     }
     for (uint32_t c = tid; c < (uint32_t)kCompStride; c += B) {
         double *r = reinterpret_cast<double *>(smem + G::oComp + c * 16);
@@ -497,7 +510,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 
     // Everything the lap step of one slot reads from LDS.
     struct SlotIn {
-        uint32_t pitw;          // pit threshold << 16 | "the DNF draw always hits"
+        uint32_t pitw;          // pit threshold << 16
         uint32_t tdnf;          // DNF draw threshold (32 bits)
         double last, var, base, eff, cdelta, drs;
         uint32_t la;            // byte offset of the driver's LAST row
@@ -519,7 +532,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 
     for (uint32_t batch = block_index; batch < n_batches; batch += n_blocks) {
         const uint64_t local = (uint64_t)batch * (uint64_t)B + (uint64_t)tid;
-        if (local >= n_sims) continue;
+        // A lane past the end of the run still runs a race while any lane of its wave has one to run -- the wave's
+        // lanes work for each other in the event handler (lane = car) -- but records nothing.
+        const bool live = local < n_sims;
+        if (!MCGP_ANY(live)) continue;
         const uint64_t sim = sim_offset + local;
         const uint32_t c0 = (uint32_t)sim, c1 = (uint32_t)(sim >> 32);
 
@@ -679,6 +695,100 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const bool sc = !red && (uint64_t)e1 < t_sc;
                 const bool vsc = !red && !sc && (uint64_t)e2 < t_vsc;
                 MCGP_STAT(12, red || sc || vsc);
+#if MCGP_COOPERATIVE_EVENTS
+                // An event is rare per simulation (2.7 % of laps on the benchmark fields) but not per wave: 83 % of
+                // wave-laps have one in SOME lane, and a handler run by every lane for the sake of ~2 of them was a
+                // tenth of the kernel.  So the wave turns the problem round: a lane with an event parks its field in
+                // the wave's window of the W plane (free outside the overtake passes), the wave handles one such field
+                // at a time with LANE = CAR -- the leader is a ballot + readlane, a car's place among the running cars
+                // a mbcnt, the neighbour's new time a bpermute -- and the lane takes its field back.
+                const bool evt = !(MCGP_SKIP & 2) && (red || sc || vsc);
+                const unsigned long long emask = __ballot(evt);
+                if (emask != 0ull) {
+                    constexpr int kRowsPerField = (12 * N <= 256) ? 1 : 2;      // cum (8 N bytes) and pk (4 N) of one field
+                    constexpr int kFields = kWordRows / kRowsPerField;          // fields parked at a time
+                    constexpr uint32_t oPk = kRowsPerField == 1 ? 8u * N : (uint32_t)(B * 4);
+                    const uint32_t lane = tid & 63u;
+                    const uint32_t wbase = G::oW + (tid4 & ~255u);              // this wave's 256-byte window of row 0
+                    const bool dec_age = sc || (vsc && (uint64_t)e3 < t_vsc_tire);
+                    const uint32_t flags = (red ? 1u : 0u) | (vsc ? 4u : 0u) | (dec_age ? 8u : 0u);
+                    const uint32_t newc = stint_compound(track, remaining_laps);
+                    const uint32_t red_bits = (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
+                    unsigned long long todo = emask, tiemask = 0ull;
+                    do {
+                        unsigned long long rest = todo;                         // `todo` without its kFields lowest set bits
+#pragma unroll 1
+                        for (int k = 0; k < kFields && rest != 0ull; ++k) rest &= rest - 1ull;
+                        const unsigned long long cur = todo & ~rest;
+                        const bool mine = evt && ((cur >> lane) & 1ull);
+                        const uint32_t my_base = wbase + (uint32_t)__popcll(cur & ((1ull << lane) - 1ull)) * (uint32_t)(kRowsPerField * B * 4);
+                        if (mine) {
+#pragma unroll
+                            for (int i = 0; i < N; ++i) {
+                                lds_st<double>(my_base + 8u * i, cum[i]);
+                                lds_st<uint32_t>(my_base + oPk + 4u * i, pk[i]);
+                            }
+                        }
+                        wave_sync();
+                        uint32_t field = 0u;
+                        for (unsigned long long mm = cur; mm != 0ull; mm &= mm - 1ull, ++field) {
+                            const int L = __ffsll((long long)mm) - 1;                               // the lane whose field this is
+                            const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)flags, L);
+                            const bool red_L = fl & 1u, vsc_L = fl & 4u;
+                            const uint32_t dec_unit = (fl & 8u) ? (1u << k3AgeShift) : 0u;
+                            const double step = red_L ? 0.1 : 0.5;
+                            const uint32_t base = wbase + field * (uint32_t)(kRowsPerField * B * 4);
+                            bool tie_here = false;
+                            if (lane < (uint32_t)N) {
+                                const double t = lds_ld<double>(base + 8u * lane);
+                                const uint32_t p = lds_ld<uint32_t>(base + oPk + 4u * lane);
+                                const bool act = !(p & k3Dnf);
+                                const unsigned long long am = __ballot(act);                         // the running cars
+                                if (am != 0ull) {
+                                    const double leader = readlane_f64(t, __ffsll((long long)am) - 1);
+                                    const unsigned long long below = am & ((1ull << lane) - 1ull);   // running cars ahead of this one
+                                    const double kd = (double)__popcll(below);
+                                    const double nt_fixed = leader + kd * step;                      // :363 / :412
+                                    const double gap = t - leader;
+                                    const double nt_vsc = leader + gap * 0.8;                        // :386-387
+                                    const double nt = vsc_L ? nt_vsc : nt_fixed;
+                                    // x0.8 may round two running cars onto one time: compare with the running car ahead
+                                    const double pn = bpermute_f64(nt, below ? 63 - __clzll((long long)below) : 0);
+                                    tie_here = act && below != 0ull && pn == nt;
+                                    const double tbl = nt - leader;                                  // :371 / :388 / :413
+                                    uint32_t q = (p & ~k3Dirty) | ((tbl > 0 && tbl < dirty_thr) ? k3Dirty : 0u);
+                                    const uint32_t agef = q & k3AgeMask;
+                                    q -= agef < dec_unit ? agef : dec_unit;                          // max(0, tire_age - 1), :375 / :393-395
+                                    const uint32_t q_red = (q & ~(k3CompMask | k3AgeMask)) | red_bits;   // :414-429
+                                    q = red_L ? q_red : q;
+                                    lds_st<double>(base + 8u * lane, act ? nt : t);
+                                    lds_st<uint32_t>(base + oPk + 4u * lane, act ? q : p);
+                                }
+                            }
+                            // (every lane of the wave records the verdict: the lane whose field this is may not be a car lane)
+                            if (__ballot(tie_here) != 0ull) tiemask |= 1ull << L;
+                        }
+                        wave_sync();
+                        if (mine) {
+#pragma unroll
+                            for (int i = 0; i < N; ++i) {
+                                cum[i] = lds_ld<double>(my_base + 8u * i);
+                                pk[i] = lds_ld<uint32_t>(my_base + oPk + 4u * i);
+                            }
+                        }
+                        wave_sync();                                        // before the next batch of fields reuses the window
+                        todo = rest;
+                    } while (todo != 0ull);
+                    if (evt) {
+                        drs_disabled_until = lap + (vsc ? 1 : 2);
+                        // Re-spacing keeps the running cars' relative order (the only order the lap loop below needs;
+                        // the full order is rebuilt after it), and the FIELD ORDER that addresses this lap's draws stays
+                        // what the last lap left.  Equal times must fall back to grid order: re-sort only then (the
+                        // oracle does the same).
+                        if ((tiemask >> lane) & 1ull) transposition_sort<N>(cum, pk);
+                    }
+                }
+#else
                 if (!(MCGP_SKIP & 2) && (red || sc || vsc)) {
                     // Only a few lanes of a wave are in here, but the wave pays for every instruction: the handlers
                     // (:334-431) are one pass over the ranks without branches.  Running cars are re-spaced behind the
@@ -722,6 +832,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     // equal times must fall back to grid order: re-sort only then (the oracle does the same).
                     if (tie) transposition_sort<N>(cum, pk);
                 }
+#endif
             }
 
             // ---- every running car's lap (:179-223) with its pit stop (:433-494), in time-rank order ----
@@ -767,8 +878,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const uint32_t p = pk[i];
                         const uint32_t wd = w[j >> 1][2 * (j & 1)];
                         const bool active = !(p & k3Dnf);                   // running at the start of the lap
-                        // this lap's DNF draw (:194-197): u < p  <=>  word < ceil(p 2^32), or p >= 1
-                        const bool dnf_hit = lt_u64(wd, s.tdnf, s.pitw & 1u);
+                        // this lap's DNF draw (:194-197): u < p  <=>  word < ceil(p 2^32)  (p < 1 here: a field with a
+                        // driver who retires with certainty every lap is served by the generic kernel, see mcgp_hip.hip)
+                        const bool dnf_hit = wd < s.tdnf;
                         const bool retire = active && dnf_hit;
                         const bool run = active && !dnf_hit;
                         const double ahead_last = carry;                    // last lap of the running car ahead  :179-183
@@ -793,9 +905,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         pin(p_run);              // both computed for every lane: the merge below stays a pair of selects
                         pin(p_ret);
                         pk[i] = run ? p_run : retire ? p_ret : p;
-                        // x + 0.0 == x for the finite, non-negative times here: cars that do not run keep their time
-                        const double t = cum[i] + (run ? lap_time : 0.0);
-                        cum[i] = t + (pit ? pit_loss : 0.0);                                        // :464
+                        const double t_run = cum[i] + lap_time;                                     // :218
+                        const double t_pit = t_run + pit_loss;                                      // :464
+                        cum[i] = pit ? t_pit : run ? t_run : cum[i];                                // (pit implies run)
                         pin(cum[i]);             // done HERE: not sunk, with its masks and lap time, to where it is used
                         lds_st<double>(G::oLast + s.la, lap_time);                                  // :219
                     }
@@ -976,6 +1088,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll 1
         for (int p = 0; p < N; ++p) {
             const uint32_t d = lds_ld<uint32_t>(l_row(p)) & 31u;
+            if (!live) break;
             atomicAdd(&s_hist[d * N + p], 1u);                       // reference :93-94
             if (orders) {
                 if (dword_orders) {

@@ -59,5 +59,11 @@ def run(case, n_sims, seed, sim_offset=0, set_pop=None, fixed_grid=None):
     rc = lib().emu_run(C.byref(p.cfg), C.byref(p.drv), _dptr(g), C.c_uint32(n), C.c_uint64(n_sims),
                        C.c_uint64(sim_offset), C.c_uint64(seed), hist.ctypes.data_as(C.c_void_p),
                        orders.ctypes.data_as(C.c_void_p), fg, C.byref(err))
+    if rc == -100:
+        raise NotServed(err.value.decode())
     assert rc == 0, err.value
     return hist.astype(np.int64), orders
+
+
+class NotServed(Exception):
+    """The register kernel hands this problem to the generic kernel (csrc: reg_kernel_serves)."""

@@ -23,6 +23,7 @@ unsigned long long emu_trace_sims = 0, emu_trace_laps = 0;
         if (emu_trace_buf && (unsigned long long)(sim) < emu_trace_sims && (unsigned long long)(lap) < emu_trace_laps) \
             emu_trace_buf[((unsigned long long)(sim) * emu_trace_laps + (lap)) * 3 + (pass)] = (unsigned char)((n_cand) + 1); \
     } while (0)
+#define MCGP_COOPERATIVE_EVENTS 0        // threads run one at a time here: every lane handles its own event
 #include "race_isa_host.h"
 
 #include "../../monte_carlo_gp_amd/csrc/params_build.h"
@@ -104,6 +105,7 @@ extern "C" int emu_run(const mcgp_config *cfg, const mcgp_drivers *drv, const do
     *err = none;
     const int rc = mcgp::build_params(cfg, drv, grid_probs, n, &kp, err);
     if (rc != MCGP_OK) return rc;
+    if (!mcgp::reg_kernel_serves(kp)) { *err = "served by the generic kernel (a DNF probability >= 1)"; return -100; }
     threadIdx = {0, 0, 0};
     blockIdx = {0, 0, 0};
     blockDim = {1, 1, 1};
