@@ -21,7 +21,7 @@
 //     W    [8][B]  u32   draw words of the overtake attempts of one pass (8 at a time)
 // with row stride = the block size B (bank = f(lane) only: conflict-free gathers by driver index), plus the
 // block-shared tables: inverse-normal cubic, per-driver {variance, base pace}, {base pace, degradation} x 2^31,
-// per-(compound, driver) {degradation x factor, pit threshold, DNF threshold}, per-compound pace delta, the
+// per-(compound, driver) {degradation x factor, pit threshold, DNF threshold}, per-compound pace delta, the pit rule, the
 // n x n histogram (u32) and the transposed grid matrix.
 //
 // Random draws of a lap are addressed by the car's PLACE in the field order (its register index): the block of
@@ -92,7 +92,7 @@ constexpr int kNumCompounds = 5;
 __host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
 {
     return (size_t)kNormalRows * 16 + (size_t)n * 16 + (size_t)(kMaxCars + n) * 16 +
-           (size_t)((kNumCompounds - 1) * kMaxCars + n) * 16 + kCompStride * 16 + 64 + align16((size_t)n * n * 4) +
+           (size_t)((kNumCompounds - 1) * kMaxCars + n) * 16 + kCompStride * 16 + 64 + 128 + align16((size_t)n * n * 4) +
            (size_t)n * n * 8;
 }
 // Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this).
@@ -130,7 +130,8 @@ struct RegGeo {
     static constexpr uint32_t oComp = oIc + ((kNumCompounds - 1) * kMaxCars + N) * 16;   // {delta f64, pad} x 8, 16 B each
     static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}              (lap time)
     static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, pad}, {drs_delta 2^31, pad}         (overtake pace)
-    static constexpr uint32_t oHist = oDrsB + 32;                 // u32[N x N]
+    static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
+    static constexpr uint32_t oHist = oLut + 128;                 // u32[N x N]
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
     static constexpr uint32_t oW = oGrid + N * N * 8;             // [kWordRows][B] u32
     static constexpr uint32_t oLast = oW + (uint32_t)kWordRows * B * 4;      // [N][B] f64
@@ -360,30 +361,27 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
     }
 }
 
-// Compound fitted at a pit stop (reference :469-490) as a function of the dry compounds already used
-// (3 bits) -- everything else it depends on is the same for the whole wave in a given lap, so the
-// rule is evaluated 8 times on the scalar unit and packed 3 bits per entry:
-//   lut_comp  bits [3u..3u+2] = new compound,  lut_used bits [3u..3u+2] = dry compounds used afterwards
-__device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uint32_t pop_sh, uint32_t pop_mh,
-                                              uint32_t &lut_comp, uint32_t &lut_used)
+// Compound fitted at a pit stop (reference :469-490) as a function of the dry compounds already used (3 bits).
+// Everything else it depends on is the same for the whole wave in a given lap, and the remaining laps matter only
+// through four regimes (> 30, 21..30, 16..20, <= 15: the thresholds of :471-477 and :485), so the rule is tabulated
+// once per block: 4 regimes x 8 used-sets, each entry the new compound and used-set bits where pk keeps them.
+__host__ __device__ constexpr int pit_regime(int remaining_laps)
 {
-    lut_comp = 0u;
-    lut_used = 0u;
-    const uint32_t stint = stint_compound(track, remaining_laps);
-#pragma unroll
-    for (uint32_t used = 0; used < 8; ++used) {
-        uint32_t newc = stint;
-        // two-compound rule, dry races only (:481-490): exactly one dry compound used so far and the
-        // stint rule would fit it again -> take another one
-        if (track == 0 && __builtin_popcount(used) == 1 && ((used >> newc) & 1u)) {
-            const uint32_t avail = 7u & ~used;
-            const uint32_t popped = avail == 5u ? pop_sh : avail == 6u ? pop_mh : 0u;
-            if (remaining_laps > 20) newc = (avail & 2u) ? 1u : popped;
-            else newc = (avail & 1u) ? 0u : popped;
-        }
-        lut_comp |= newc << (3 * used);
-        lut_used |= ((used | (1u << newc)) & 7u) << (3 * used);
+    return remaining_laps > 30 ? 0 : remaining_laps > 20 ? 1 : remaining_laps > 15 ? 2 : 3;
+}
+__device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_t used, uint32_t pop_sh, uint32_t pop_mh)
+{
+    const int remaining_laps = regime == 0 ? 31 : regime == 1 ? 21 : regime == 2 ? 16 : 0;     // one value per regime
+    uint32_t newc = stint_compound(track, remaining_laps);
+    // two-compound rule, dry races only (:481-490): exactly one dry compound used so far and the stint rule would
+    // fit it again -> take another one
+    if (track == 0 && __popc(used) == 1 && ((used >> newc) & 1u)) {
+        const uint32_t avail = 7u & ~used;
+        const uint32_t popped = avail == 5u ? pop_sh : avail == 6u ? pop_mh : 0u;
+        if (remaining_laps > 20) newc = (avail & 2u) ? 1u : popped;
+        else newc = (avail & 1u) ? 0u : popped;
     }
+    return (newc << k3CompShift) | ((used | (1u << newc)) & k3UsedMask);
 }
 
 // The instruction scheduler may not move anything across this point (no instruction is emitted).
@@ -394,7 +392,7 @@ __device__ __forceinline__ void pit_rule_luts(int track, int remaining_laps, uin
 #define MCGP_STEP_BATCH 4          // slots whose LDS gathers (and Philox blocks) are in flight together in the lap step
 #endif
 #ifndef MCGP_PACE_BATCH
-#define MCGP_PACE_BATCH 5          // slots whose pace gathers are in flight together in an overtake pass
+#define MCGP_PACE_BATCH 10         // slots whose pace gathers are in flight together in an overtake pass
 #endif
 
 // The register kernel keeps the per-lap DNF threshold in 32 bits: a driver who retires with CERTAINTY on every lap
@@ -448,6 +446,9 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         // DNF draw threshold, 32 bits: ceil(p 2^32) for p < 1 (reg_kernel_serves() keeps p >= 1 away from this kernel)
         *reinterpret_cast<uint32_t *>(r + 12) = (uint32_t)P->t_dnf[d];                              // reference :190-194
     }
+    for (uint32_t i = tid; i < 32u; i += B)
+        *reinterpret_cast<uint32_t *>(smem + G::oLut + i * 4) =
+            pit_rule_word(P->track, (int)(i >> 3), i & 7u, (uint32_t)P->pop_sh, (uint32_t)P->pop_mh);
     for (uint32_t c = tid; c < (uint32_t)kCompStride; c += B) {
         double *r = reinterpret_cast<double *>(smem + G::oComp + c * 16);
         r[0] = P->comp_delta[c];
@@ -505,7 +506,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     const double dirty_thr = P->dirty_thr;
     const double dirty_pen = P->dirty_pen;
     const float kNaN = __uint_as_float(0x7fc00000u);
-    const uint32_t pop_sh = (uint32_t)P->pop_sh, pop_mh = (uint32_t)P->pop_mh;
     const uint64_t t_red = P->t_red, t_sc = P->t_sc, t_vsc = P->t_vsc, t_vsc_tire = P->t_vsc_tire;
 
     // Everything the lap step of one slot reads from LDS.
@@ -514,9 +514,11 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         uint32_t tdnf;          // DNF draw threshold (32 bits)
         double last, var, base, eff, cdelta, drs;
         uint32_t la;            // byte offset of the driver's LAST row
+        uint32_t fit;           // compound and used-set a pit stop on this lap would leave, positioned as in pk
     };
-    auto load_slot = [&](uint32_t p) -> SlotIn {
+    auto load_slot = [&](uint32_t p, uint32_t lut_base) -> SlotIn {
         SlotIn r;
+        r.fit = lds_ld<uint32_t>(((p & k3UsedMask) << 2) + lut_base);
         r.la = last_of(p);
         r.last = lds_ld<double>(G::oLast + r.la);
         const uint32_t id16 = (p >> 6) & 0x1F0u;                                  // 16 x driver
@@ -847,8 +849,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 if (!(fuel > 0)) fuel = 0.0;
                 const double fuel_effect = (110.0 - fuel) * 0.03;
                 const bool pit_window = remaining_laps > 5;                                     // :451
-                uint32_t lut_comp, lut_used;
-                pit_rule_luts(track, remaining_laps, pop_sh, pop_mh, lut_comp, lut_used);
+                const uint32_t lut_base = G::oLut + 32u * (uint32_t)pit_regime(remaining_laps);  // this lap's row of the pit rule
                 const uint32_t retire_bits = k3Dnf | ((uint32_t)lap << k3AgeShift);
                 double carry = 0.0;
 #pragma unroll
@@ -857,7 +858,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     SlotIn in[MCGP_STEP_BATCH];
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j)
-                        if (i0 + j < N) in[j] = load_slot(pk[i0 + j]);
+                        if (i0 + j < N) in[j] = load_slot(pk[i0 + j], lut_base);
                     uint32_t w[MCGP_STEP_BATCH / 2][4];
 #pragma unroll
                     for (int b = 0; b < MCGP_STEP_BATCH / 2; ++b) {
@@ -881,7 +882,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         // this lap's DNF draw (:194-197): u < p  <=>  word < ceil(p 2^32)  (p < 1 here: a field with a
                         // driver who retires with certainty every lap is served by the generic kernel, see mcgp_hip.hip)
                         const bool dnf_hit = wd < s.tdnf;
-                        const bool retire = active && dnf_hit;
                         const bool run = active && !dnf_hit;
                         const double ahead_last = carry;                    // last lap of the running car ahead  :179-183
                         carry = active ? s.last : carry;
@@ -895,16 +895,15 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const bool in_dirty = (p & k3Dirty) && ahead_last > 0;                      // :209-212
                         const double lap_time = in_dirty ? held : clean;
                         // pit stop (:450-492): (tyre age + 1) << 16 against the pit word; compound and used-set from
-                        // the per-lap rule tables
+                        // the rule table (pit_rule_word)
                         const bool pit = run && pit_window && (agef + (1u << k3AgeShift)) > s.pitw;
-                        const uint32_t u3 = (p & k3UsedMask) * 3u;
-                        const uint32_t newc = (lut_comp >> u3) & 7u, newu = (lut_used >> u3) & 7u;
-                        const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | (newc << k3CompShift) | newu;
+                        const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | s.fit;
                         uint32_t p_run = pit ? p_pit : p + (1u << k3AgeShift);
                         uint32_t p_ret = (p & ~k3AgeMask) | retire_bits;
                         pin(p_run);              // both computed for every lane: the merge below stays a pair of selects
                         pin(p_ret);
-                        pk[i] = run ? p_run : retire ? p_ret : p;
+                        const uint32_t p_act = dnf_hit ? p_ret : p_run;
+                        pk[i] = active ? p_act : p;
                         const double t_run = cum[i] + lap_time;                                     // :218
                         const double t_pit = t_run + pit_loss;                                      // :464
                         cum[i] = pit ? t_pit : run ? t_run : cum[i];                                // (pit implies run)
