@@ -14,12 +14,14 @@ per step when N > 1).  Simulations shard over ranks by global simulation id with
 no other exchange ("weak" scaling: per-GPU work is fixed).
 
 The JSON line printed by rank 0 carries, besides the contract fields,
-  roofline       algorithmic HBM bytes (20 B per simulation) / live kernel time (hipEvents on the
-                 launch stream) against the 8 TB/s HBM peak, with `traffic` = HBM bytes per launch from the PMC
-                 passes -- evidence that the path is NOT memory bound
-  roofline_valu  the binding resource: wave-level VALU instructions per launch (PMC) / live kernel time against
-                 1024 SIMDs x 2.4 GHz / 2 cycles; counters are quoted only when profiles/r2_counters.json carries
-                 the source hash of the loaded library (else null, reason in roofline.counters_note)
+  roofline       the BINDING resource, VALU instruction issue: wave-level VALU instructions per launch (PMC) / live
+                 kernel time (hipEvents on the launch stream) against 1024 SIMDs x 2.4 GHz / 2 cycles (the guide's
+                 SIMD-32 rate; `frac`), and against the 4-cycle rate that the datasheet's 78.6 TFLOP/s of vector FP64
+                 implies (`frac_at_fp64_rate`), with the PMC's own VALUBusy beside them; `traffic` = HBM bytes per
+                 launch from the PMC passes; roofline.hbm_nominal = the 20 algorithmic bytes per simulation
+                 against the 8 TB/s HBM peak -- evidence that the path is NOT memory bound.  Counters are quoted only
+                 when profiles/r3_counters.json carries the source hash of the loaded library (else null, reason in
+                 roofline.counters_note)
   workloads.S78  BASELINE configs[2] (78-lap Monaco parameters), three steps in the same run        (N = 1 only)
   orders_mode    the same workload with the 20 B per simulation actually written                    (N = 1 only)
   cpu_baseline   the CPU oracle on this box's host cores, bounded samples: MT back-end on one core (the
@@ -42,6 +44,10 @@ SIMS_PER_STEP = 10_000_000
 ALGORITHMIC_BYTES_PER_SIM = 20          # the n x u8 finishing order, SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TINST = 1024 * 2.4e9 / 2 / 1e12   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+# the rate the datasheet's vector FP64 peak implies: 78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz, i.e. one
+# wave64 instruction per 4 cycles -- also what the PMC's VALUBusy (4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles) measures
+VALU_PEAK_TINST_4CYCLE = 1024 * 2.4e9 / 4 / 1e12
+COUNTERS_FILE = 'r3_counters.json'
 
 
 def load_workload(name):
@@ -157,7 +163,7 @@ def profiled_counters(workload, per_gpu, lib_overridden):
     """PMC-derived figures kept under profiles/ (rocprofv3 --pmc passes, tools/summarize_profiles.py), quoted
     ONLY when the file is stamped with the hash of the kernel sources the loaded library was built from."""
     from monte_carlo_gp_amd import _native as N
-    path = os.path.join(ROOT, 'profiles', 'r2_counters.json')
+    path = os.path.join(ROOT, 'profiles', COUNTERS_FILE)
     if lib_overridden:
         return None, 'MCGP_LIB is set: counters under profiles/ belong to the product build'
     try:
@@ -166,11 +172,11 @@ def profiled_counters(workload, per_gpu, lib_overridden):
     except (OSError, ValueError) as e:
         return None, f'no usable {os.path.relpath(path, ROOT)}: {e}'
     if pc.get('source_hash') != N.source_hash():
-        return None, (f"profiles/r2_counters.json was taken from sources {pc.get('source_hash')}, "
+        return None, (f"profiles/r3_counters.json was taken from sources {pc.get('source_hash')}, "
                       f'the loaded library is built from {N.source_hash()}: re-profile')
     w = pc.get('workloads', {}).get(workload)
     if not w or w.get('sims_per_launch') != per_gpu:
-        return None, f'profiles/r2_counters.json has no {workload} entry at {per_gpu} simulations per launch'
+        return None, f'profiles/r3_counters.json has no {workload} entry at {per_gpu} simulations per launch'
     return w, None
 
 
@@ -197,6 +203,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     lib = N.lib()                            # builds once per node (flock) BEFORE anything touches the GPU
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_py                     # ... and so does the CPU oracle of the cpu_baseline leg: a GPU-initialised
+        oracle_py.lib()                      # process must not fork + exec make later
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     # Rehearsal knobs (one-GPU box): MCGP_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and reduces over
@@ -294,18 +303,33 @@ def main():
         n, L, kavg_ms, hist = r['n'], r['L'], r['kernel_ms'], r['hist']
         achieved = per_gpu * ALGORITHMIC_BYTES_PER_SIM / (kavg_ms * 1e-3) / 1e9
         pc, why_not = profiled_counters(args.workload, per_gpu, bool(os.environ.get('MCGP_LIB')))
-        traffic = valu = None
+        traffic = None
+        roof = {'bound': 'valu-issue', 'achieved': None, 'peak': VALU_PEAK_TINST, 'unit': 'T wave-instructions/s',
+                'frac': None, 'traffic': None}
         if pc:
             traffic = pc.get('hbm_bytes_per_launch')
             insts = pc['SQ_INSTS_VALU']
-            # VALU issue roofline (the binding resource): wave-level VALU instructions per launch (a property of
-            # the workload and the code, stamped with the source hash) over the LIVE kernel time; peak = 1024
-            # SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cycles)
-            valu = {'bound': 'valu-issue', 'achieved': insts / (kavg_ms * 1e-3) / 1e12, 'peak': VALU_PEAK_TINST,
-                    'unit': 'T wave-instructions/s', 'frac': insts / (kavg_ms * 1e-3) / 1e12 / VALU_PEAK_TINST,
-                    'valu_insts_per_launch': insts, 'active_lane_ratio': pc.get('active_lane_ratio'),
-                    'valu_busy_profiled': pc.get('valu_busy'), 'source_hash': pc.get('source_hash'),
-                    'counters': 'profiles/r2_counters.json (rocprofv3 --pmc, tools/profile_r2.sh), same source hash as the loaded library'}
+            rate = insts / (kavg_ms * 1e-3) / 1e12
+            # VALU issue roofline (the binding resource): wave-level VALU instructions per launch (a property of the
+            # workload and the code, stamped with the source hash) over the LIVE kernel time
+            roof.update({'achieved': rate, 'frac': rate / VALU_PEAK_TINST, 'traffic': traffic,
+                         'peak_at_fp64_rate': VALU_PEAK_TINST_4CYCLE, 'frac_at_fp64_rate': rate / VALU_PEAK_TINST_4CYCLE,
+                         'valu_busy_profiled': pc.get('valu_busy'), 'valu_insts_per_launch': insts,
+                         'active_lane_ratio': pc.get('active_lane_ratio'), 'waves_per_simd': pc.get('waves_per_simd'),
+                         'scratch_bytes_per_lane': int(pc.get('kernel', {}).get('Scratch_Size', 0) or 0),
+                         'source_hash': pc.get('source_hash'),
+                         'counters': 'profiles/r3_counters.json (rocprofv3 --pmc, tools/profile_r3.sh), same source hash as the loaded library'})
+        roof.update({
+            'kernel': r['kernel'], 'kernel_ms_avg': kavg_ms, 'counters_note': why_not,
+            'peak_note': 'peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: SIMD-32); '
+                         'peak_at_fp64_rate = / 4 cycles, the rate behind the 78.6 TFLOP/s vector FP64 peak and behind '
+                         "the profiler's VALUBusy; the kernel's instructions are binary64 / VOP3 ones for the most part",
+            'hbm_nominal': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': achieved / HBM_PEAK_GBS,
+                            'note': 'nominal: 20 algorithmic bytes per simulation (the finishing order) over the kernel '
+                                    'time; in this histogram-only mode they are not written (3.2 KB per launch is). '
+                                    'orders_mode times the run that does write them; `traffic` above is the measured '
+                                    'HBM traffic per launch (block prologues, histogram atomics, register spills)'}})
         out = {
             'metric': f'race-simulations/sec ({n} drivers, {L} laps)',
             'value': r['total'] / r['elapsed'],
@@ -320,20 +344,13 @@ def main():
             'vs_baseline': None,
             'dtype': 'f64',
             'dtype_note': 'race state and every comparison in IEEE binary64 (as the reference); random deviates carry '
-                          '32 bits: uniforms w/2^32, normals from a binary32 piecewise-cubic inverse CDF (|err| <= 4.8e-7)',
+                          '32 bits: uniforms w/2^32, normals from a binary32 piecewise-cubic inverse CDF (|err| <= 4.8e-7); '
+                          'measured effect of that substitution on results: profiles/r3_deviate_bias.txt',
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {n} drivers, {L} laps, {per_gpu} simulations per GPU per step, '
                                    f'fixed Elo grid, seed {r["seed"]}',
                        'sims_per_gpu_per_step': per_gpu, 'parallelism': f'sims sharded over {world} GPU(s)'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': r['kernel'], 'kernel_ms_avg': kavg_ms,
-                         'note': 'nominal: 20 algorithmic bytes per simulation (the finishing order) over the kernel time; '
-                                 'in this histogram-only mode they are not written (3.2 KB per launch is). The path is '
-                                 'VALU-issue bound, not HBM bound: see roofline_valu; orders_mode times the run that '
-                                 'does write the 20 B per simulation',
-                         'counters_note': why_not},
-            'roofline_valu': valu,
+            'roofline': roof,
             'valu': {'car_laps_per_s': per_gpu * n * L / (kavg_ms * 1e-3),
                      'sims_per_s_kernel_only': per_gpu / (kavg_ms * 1e-3), 'launch': r['launch']},
             'win_probability_top3': {r['drivers'][i]: float(hist[i, 0]) / r['total'] for i in np.argsort(-hist[:, 0])[:3]},

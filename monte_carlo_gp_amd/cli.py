@@ -1,7 +1,8 @@
 """Command line: the reference's main.py / backtest.py flags, working offline.
 
     python -m monte_carlo_gp_amd.cli predict  --race Bahrain --season 2024 --simulations 10000 --seed 42 --offline
-    python -m monte_carlo_gp_amd.cli backtest --seasons 2024 --seed 42 --simulations 10000000
+    python -m monte_carlo_gp_amd.cli backtest --seasons 2024 --seed 42 --simulations 10000000 [--fixtures DIR]
+    python -m monte_carlo_gp_amd.cli export-fixtures --seasons 2024 --out DIR
 
 Flags kept from the reference: --season, --race, --prediction-point, --simulations (main.py:8-16);
 --seasons, --seed (backtest.py:9-14).  Unlike the reference, --simulations and --seed reach the
@@ -22,7 +23,7 @@ import time
 
 from . import config as K
 from .predictor import F1Predictor, circuit_info
-from .validation import brier_score, podium_accuracy
+from .validation import brier_score, calibration_analysis, podium_accuracy
 
 
 def synthetic_fixture(drivers=None) -> dict:
@@ -131,13 +132,27 @@ def season_fixtures(season: int, entries: list) -> list:
     return out
 
 
-def backtest_jobs(seasons, seed):
-    """(season, result entry, per-race seed, race fixture) for every race of the sweep, in calendar order."""
+def fixture_file_name(season: int, index: int, race: str) -> str:
+    """File name of a per-race fixture in a --fixtures directory: <season>_<NN>_<race with underscores>.json."""
+    return f"{season}_{index + 1:02d}_{race.replace(' ', '_')}.json"
+
+
+def backtest_jobs(seasons, seed, fixtures_dir=None):
+    """(season, result entry, per-race seed, race fixture) for every race of the sweep, in calendar order.
+
+    With fixtures_dir, a race whose file (fixture_file_name) exists there is predicted from THAT fixture -- what the
+    reference's per-race practice-session extraction (src/predictor.py:409-569, out of scope) would hand over --
+    and the others from the synthetic weekend with the evolved Elo ratings (season_fixtures)."""
     rng = random.Random(seed)
     jobs = []
     for season in seasons:
         entries = load_results(season)
-        for entry, fx in zip(entries, season_fixtures(season, entries)):
+        for idx, (entry, fx) in enumerate(zip(entries, season_fixtures(season, entries))):
+            if fixtures_dir:
+                path = os.path.join(fixtures_dir, fixture_file_name(season, idx, entry['race']))
+                if os.path.exists(path):
+                    with open(path) as f:
+                        fx = dict(json.load(f), fixture_file=path)
             jobs.append((season, entry, rng.getrandbits(63), fx))
     return jobs
 
@@ -147,7 +162,8 @@ def shard_jobs(jobs, rank, world):
     return [(i, j) for i, j in enumerate(jobs) if i % world == rank]
 
 
-def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, predictor_factory=None):
+def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, predictor_factory=None,
+             fixtures_dir=None):
     """Sweep one prediction per race of each season and score it (reference validation.py:161-209).
 
     A fresh predictor per race, fed that race's fixture (season_fixtures: Elo evolved over the earlier
@@ -157,7 +173,7 @@ def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, p
     all_gather_object of the per-race rows at the end).  Returns the reference's result dict plus
     per-race rows.
     """
-    mine = shard_jobs(backtest_jobs(seasons, seed), rank, world)
+    mine = shard_jobs(backtest_jobs(seasons, seed, fixtures_dir), rank, world)
     factory = predictor_factory or (lambda: F1Predictor(device=device))
     rows = []
     for i, (season, entry, race_seed, fixture) in mine:
@@ -165,7 +181,9 @@ def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, p
                                         seed=race_seed)
         rows.append((i, dict(race=entry['race'], season=season, laps=circuit_info(entry['race'])['laps'],
                              pole=res['pole_probabilities'], win=res['win_probabilities'],
-                             podium_probabilities=res['podium_probabilities'], actual=entry)))
+                             podium_probabilities=res['podium_probabilities'], actual=entry, seed=race_seed,
+                             fixture='synthetic' if fixture.get('synthetic') and not fixture.get('fixture_file')
+                             else fixture.get('fixture_file', 'given'))))
     from .distributed import wants_process_group
     if wants_process_group(world):
         import torch.distributed as dist
@@ -180,8 +198,12 @@ def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, p
         'pole_brier': float(brier_score([p['pole_probabilities'] for p in preds], [a['pole'] for a in acts])),
         'win_brier': float(brier_score([p['win_probabilities'] for p in preds], [a['winner'] for a in acts])),
         'podium_accuracy': podium_accuracy(preds, acts),
+        'calibration_curve': calibration_analysis([dict(win_probabilities=r['win']) for r in rows], acts),
         'n_races': len(rows),
         'races': rows,
+        # what these scores are NOT: the reference's backtest reads live FastF1 sessions and results; here the weekends
+        # are fixtures and the outcomes a hand-entered file, so the numbers are not comparable with a reference run
+        'reference_comparable': False,
     }
 
 
@@ -206,21 +228,44 @@ def cmd_backtest(args) -> int:
             torch.cuda.set_device(device)
             dist.init_process_group('nccl', device_id=torch.device('cuda', device))
     t0 = time.perf_counter()
-    res = backtest(args.seasons, args.seed, args.simulations, device, rank, world)
+    res = backtest(args.seasons, args.seed, args.simulations, device, rank, world, fixtures_dir=args.fixtures)
     dt = time.perf_counter() - t0
     if rank == 0:
-        print(f"\n{'=' * 60}\nBacktest (offline sweep: synthetic weekends, Elo evolved race by race, hand-entered outcomes)\n"
+        given = sum(1 for r in res['races'] if r['fixture'] != 'synthetic')
+        print(f"\n{'=' * 60}\nBacktest (offline sweep: {given} race fixture(s) from --fixtures, the rest synthetic weekends with Elo\n"
+              f"evolved race by race; hand-entered outcomes -- NOT comparable with the reference's live-data backtest)\n"
               f"Seasons: {args.seasons}   simulations per race: {args.simulations}\n{'=' * 60}\n")
         print(f"Races analyzed: {res['n_races']}   ({res['n_races'] * args.simulations / dt:,.0f} simulations/s overall)\n")
         print('BRIER SCORES (lower = better, 0 = perfect)\n' + '-' * 40)
         print(f"  Pole position: {res['pole_brier']:.4f}\n  Race winner:   {res['win_brier']:.4f}")
         print(f"  (Random baseline: {0.0475:.4f})\n")
         print('PODIUM ACCURACY\n' + '-' * 40 + f"\n  Correct podium picks: {res['podium_accuracy']:.1%}\n")
+        cal = res['calibration_curve']
+        if cal['prob_pred']:
+            print('CALIBRATION (win probability: predicted -> observed)\n' + '-' * 40)
+            for pp, pt in zip(cal['prob_pred'], cal['prob_true']):
+                print(f"  {pp:6.1%} -> {pt:6.1%}")
+            print()
         if args.json:
             with open(args.json, 'w') as f:
                 json.dump(res, f)
     if grouped:
         dist.destroy_process_group()
+    return 0
+
+
+def cmd_export_fixtures(args) -> int:
+    """One JSON file per race (fixture_file_name): the synthetic weekend with that race's Elo ratings -- a template
+    to replace with real practice data (base_pace / tire_deg per driver, features, weather)."""
+    os.makedirs(args.out, exist_ok=True)
+    n = 0
+    for season in args.seasons:
+        entries = load_results(season)
+        for idx, (entry, fx) in enumerate(zip(entries, season_fixtures(season, entries))):
+            with open(os.path.join(args.out, fixture_file_name(season, idx, entry['race'])), 'w') as f:
+                json.dump(fx, f, indent=1)
+            n += 1
+    print(f'{n} race fixtures written to {args.out}')
     return 0
 
 
@@ -244,7 +289,13 @@ def main(argv=None) -> int:
     b.add_argument('--simulations', type=int, default=10000)
     b.add_argument('--device', type=int, default=0)
     b.add_argument('--json', type=str, default=None)
+    b.add_argument('--fixtures', type=str, default=None,
+                   help='directory of per-race fixture files (see export-fixtures); races without a file use the synthetic weekend')
     b.set_defaults(fn=cmd_backtest)
+    e = sub.add_parser('export-fixtures', help='write the per-race fixtures of the offline sweep as editable JSON files')
+    e.add_argument('--seasons', type=int, nargs='+', default=[2024])
+    e.add_argument('--out', type=str, required=True)
+    e.set_defaults(fn=cmd_export_fixtures)
     args = ap.parse_args(argv)
     return args.fn(args)
 

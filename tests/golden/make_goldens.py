@@ -56,7 +56,7 @@ from src.simulation import RaceSimulator, RaceConfig  # noqa: E402
 from src.config import DRIVER_TEAMS, TIRE_COMPOUNDS, DEFAULT_DNF_RATES, CIRCUITS  # noqa: E402
 from src.predictor import F1Predictor  # noqa: E402
 from src.elo import F1EloSystem  # noqa: E402
-from src.validation import brier_score, podium_accuracy  # noqa: E402
+from src.validation import brier_score, podium_accuracy, calibration_analysis  # noqa: E402
 
 COMPOUND_ID = {'SOFT': 0, 'MEDIUM': 1, 'HARD': 2, 'INTERMEDIATE': 3, 'WET': 4}
 
@@ -339,6 +339,38 @@ def misc():
     e.set_recency_weight(1)
     e.update_race_ratings([(d, ((i * 3) % 20) + 1) for i, d in enumerate(drivers)])
     out['elo_after'] = e.ratings
+    # calibration_analysis (reference src/validation.py:133-158, sklearn's calibration_curve underneath): a season-sized
+    # sample (10 bins), one with a race without winner and one without probabilities, and one too small for 10 bins
+    rs = np.random.RandomState(7)
+
+    def season(n_races, n_drivers):
+        preds, acts = [], []
+        for _ in range(n_races):
+            w = rs.gamma(0.6, size=n_drivers)
+            w = w / w.sum()
+            ds = drivers[:n_drivers]
+            preds.append({'win_probabilities': {d: float(x) for d, x in zip(ds, w)}})
+            acts.append({'winner': ds[int(rs.choice(n_drivers, p=w))]})
+        return preds, acts
+    cal = {}
+    for name, (n_races, n_drivers) in {'season': (24, 20), 'small': (3, 5), 'tiny': (1, 4)}.items():
+        preds, acts = season(n_races, n_drivers)
+        if name == 'season':
+            acts[3] = {'winner': None}
+            preds[7] = {'win_probabilities': {}}
+            preds[11] = {}
+        cal[name] = dict(preds=preds, actuals=acts, result=calibration_analysis(preds, acts))
+    cal['empty'] = dict(preds=[], actuals=[], result=calibration_analysis([], []))
+    out['calibration'] = cal
+    # Elo updates from a complete ordering, for the backtest sweep's known-pairs update (reference src/elo.py:45-122)
+    e2 = F1EloSystem()
+    for i, d in enumerate(drivers):
+        e2.ratings[d] = {'quali': 1700.0 - 20.0 * i, 'race': 1650.0 - 15.0 * i}
+    e2.set_recency_weight(0, 9, 24)
+    order = [drivers[(i * 7) % 20] for i in range(20)]
+    e2.update_quali_ratings([(d, 80.0 + 0.05 * k) for k, d in enumerate(order)])      # fastest first
+    e2.update_race_ratings([(d, k + 1) for k, d in enumerate(order)])
+    out['elo_full_order'] = dict(order=order, race_index=9, total=24, after=e2.ratings)
     out['circuits'] = CIRCUITS
     out['driver_teams'] = DRIVER_TEAMS
     out['dnf_rates'] = DEFAULT_DNF_RATES

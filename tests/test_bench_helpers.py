@@ -26,11 +26,11 @@ def test_profiled_counters_are_refused_for_other_sources(tmp_path, monkeypatch):
     w, why = bench.profiled_counters('S60', 10_000_000, False)
     assert w is None and 'no usable' in why
     doc = {'source_hash': 'deadbeefdeadbeef', 'workloads': {'S60': {'sims_per_launch': 10_000_000, 'SQ_INSTS_VALU': 1.0}}}
-    (tmp_path / 'profiles' / 'r2_counters.json').write_text(json.dumps(doc))
+    (tmp_path / 'profiles' / 'r3_counters.json').write_text(json.dumps(doc))
     w, why = bench.profiled_counters('S60', 10_000_000, False)
     assert w is None and 're-profile' in why
     doc['source_hash'] = N.source_hash()
-    (tmp_path / 'profiles' / 'r2_counters.json').write_text(json.dumps(doc))
+    (tmp_path / 'profiles' / 'r3_counters.json').write_text(json.dumps(doc))
     w, why = bench.profiled_counters('S60', 10_000_000, False)
     assert why is None and w['SQ_INSTS_VALU'] == 1.0
     assert bench.profiled_counters('S60', 10_000_000, True)[0] is None              # MCGP_LIB set

@@ -65,6 +65,43 @@ def test_per_race_fixtures_follow_the_elo_trajectory():
     assert [j[3]['race_index'] for j in jobs] == list(range(24))
 
 
+def test_fixture_directory_overrides_single_races(tmp_path, capsys):
+    """`export-fixtures` writes one editable file per race; `backtest --fixtures DIR` predicts a race from its file
+    when there is one (the stand-in for the reference's per-race practice extraction, src/predictor.py:409-569)
+    and from the synthetic weekend otherwise; the sweep result carries the calibration curve of
+    reference src/validation.py:207 and says that it is not comparable with a reference run."""
+    assert cli.main(['export-fixtures', '--seasons', '2024', '--out', str(tmp_path)]) == 0
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert len(files) == 24 and files[0] == '2024_01_Bahrain.json'
+    entries = cli.load_results(2024)
+    assert json.loads((tmp_path / files[4]).read_text()) == json.loads(json.dumps(cli.season_fixtures(2024, entries)[4]))
+    # the exported files reproduce the synthetic sweep exactly ...
+    _FakePredictor.calls.clear()
+    a = cli.backtest([2024], seed=42, n_simulations=10, predictor_factory=_FakePredictor)
+    b = cli.backtest([2024], seed=42, n_simulations=10, predictor_factory=_FakePredictor, fixtures_dir=str(tmp_path))
+    for k in ('pole_brier', 'win_brier', 'podium_accuracy', 'calibration_curve'):
+        assert a[k] == b[k], k
+    assert [r['fixture'] for r in a['races']] == ['synthetic'] * 24
+    assert all(r['fixture'].endswith('.json') for r in b['races']) and a['reference_comparable'] is False
+    # ... an edited one changes its race only (the stand-in predictor's favourite is the fixture's first driver) ...
+    fx = json.loads((tmp_path / files[2]).read_text())
+    fx['drivers'] = fx['drivers'][::-1]
+    fx['practice']['base_pace'][fx['drivers'][0]] = 88.5
+    (tmp_path / files[2]).write_text(json.dumps(fx))
+    for f in files[10:]:
+        (tmp_path / f).unlink()                                       # ... and a missing one falls back
+    c = cli.backtest([2024], seed=42, n_simulations=10, predictor_factory=_FakePredictor, fixtures_dir=str(tmp_path))
+    assert [r['fixture'] == 'synthetic' for r in c['races']] == [False] * 10 + [True] * 14
+    assert [x['win'] == y['win'] for x, y in zip(a['races'], c['races'])] == [i != 2 for i in range(24)]
+    jobs = cli.backtest_jobs([2024], 42, str(tmp_path))
+    assert jobs[2][3]['practice']['base_pace'][fx['drivers'][0]] == 88.5
+    # calibration curve of the stand-in's predictions: 24 x 20 samples in 10 bins, two of them populated
+    cal = a['calibration_curve']
+    assert len(cal['prob_pred']) == 2 and cal['prob_pred'][1] == pytest.approx(0.5)
+    wins = sum(r['actual']['winner'] == 'VER' for r in a['races'])
+    assert cal['prob_true'][1] == pytest.approx(wins / 24)
+
+
 def test_results_fixture_is_flagged_and_consistent():
     races = cli.load_results(2024)
     assert len(races) == 24
@@ -103,19 +140,39 @@ def test_cli_predict_end_to_end(require_gpu, tmp_path, capsys):
 
 
 @pytest.mark.gpu
-def test_backtest_sweep_on_gpu(require_gpu):
-    res = cli.backtest([2024], seed=42, n_simulations=200000)
+def test_backtest_sweep_on_gpu_equals_the_oracle_race_by_race(require_gpu):
+    """Every race of the sweep against the CPU oracle on THAT race's inputs (its fixture's Elo ratings, its circuit,
+    its seed): the win probabilities are the oracle's counts / N exactly, and the scores follow from them."""
+    import oracle_py as O
+    from monte_carlo_gp_amd.predictor import F1Predictor
+    from monte_carlo_gp_amd.validation import brier_score
+    n_sims = 4000
+    res = cli.backtest([2024], seed=42, n_simulations=n_sims)
     assert res['n_races'] == 24
+    jobs = cli.backtest_jobs([2024], 42)
+    oracle_wins = []
+    for (season, entry, race_seed, fixture), row in zip(jobs, res['races']):
+        assert row['race'] == entry['race'] and row['seed'] == race_seed
+        inp = F1Predictor().simulator_inputs(fixture, entry['race'])
+        case = dict(config=inp['config'].__dict__, grid_probs=inp['grid_probs'], base_pace=inp['base_pace'],
+                    tire_deg=inp['tire_deg'], driver_variance=inp['driver_variance'],
+                    driver_dnf_rates=inp['driver_dnf_rates'], track_condition=inp['track_condition'])
+        ref = O.Problem(case).run(n_sims, rng=O.RNG_PHILOX, seed=race_seed)['hist']
+        win = {d: ref[i, 0] / n_sims for i, d in enumerate(inp['drivers'])}
+        assert row['win'] == win, entry['race']
+        oracle_wins.append(win)
+    assert res['win_brier'] == float(brier_score(oracle_wins, [j[1]['winner'] for j in jobs]))
     assert 0.0 < res['win_brier'] < 0.2 and 0.0 <= res['podium_accuracy'] <= 1.0
-    again = cli.backtest([2024], seed=42, n_simulations=200000)
-    assert again['win_brier'] == res['win_brier'] and again['pole_brier'] == res['pole_brier']
+    assert len(res['calibration_curve']['prob_pred']) >= 2
 
 
 @pytest.mark.gpu
 def test_backtest_sweep_full_size(require_gpu):
     """BASELINE configs[4] on one GPU: the 2024 calendar x 10^7 simulations per race (reference
-    src/validation.py:161-209), each race on its own fixture.  Scores are compared with the 2x10^5-simulation
-    sweep: same races, same fixtures, different seeds/sizes -> win probabilities agree to Monte Carlo error."""
+    src/validation.py:161-209), each race on its own fixture.  At this size the check is a property: the
+    2x10^5-simulation sweep of the same races -- whose rows the test above ties to the oracle exactly -- must agree
+    within Monte Carlo error, every race's win probabilities sum to 1, and the pole model (no Monte Carlo in it) is
+    identical."""
     import time
     t0 = time.perf_counter()
     big = cli.backtest([2024], seed=7, n_simulations=10_000_000)

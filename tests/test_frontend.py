@@ -132,3 +132,34 @@ def test_run_from_ratings_equals_oracle_on_the_device_matrix(require_gpu):
     for d in fx['drivers']:
         assert abs(a['pole_probabilities'][d] - b['pole_probabilities'][d]) <= REL_TOL * b['pole_probabilities'][d]
     assert a['win_probabilities'] == b['win_probabilities']        # same sampled grids: the matrices differ by ~1 ulp
+
+
+@pytest.mark.gpu
+def test_device_front_end_rejects_non_finite_inputs(require_gpu):
+    """an infinite rating (inf - inf in the softmax) or a NaN / infinite feature would put a NaN matrix into
+    the parameter block, which the race kernel samples uniform grids from without a word; mcgp_run rejects such a
+    matrix, and so must the front-end entry points (MCGP_E_BAD_ARG, nothing launched)."""
+    from monte_carlo_gp_amd import RaceConfig, _native as N
+    case = O.load_case('S60')
+    drivers = list(case['grid_probs'])
+    sim = RaceSimulator(RaceConfig(**case['config']), set_pop=O.load_cases()['set_pop'])
+    good = {d: 1600.0 - 10 * i for i, d in enumerate(drivers)}
+    bad_inputs = [
+        (dict(good, **{drivers[3]: float('inf')}), {}),
+        (dict(good, **{drivers[0]: float('nan')}), {}),
+        (good, {drivers[5]: dict(form_score=float('nan'))}),
+        (good, {drivers[7]: dict(teammate_delta=float('-inf'))}),
+        (good, {drivers[9]: dict(circuit_affinity=float('inf'))}),
+    ]
+    for ratings, feats in bad_inputs:
+        with pytest.raises(N.McgpError) as e:
+            sim.grid_probs_on_device(drivers, ratings, feats, {})
+        assert e.value.code == -1
+        with pytest.raises(N.McgpError) as e:
+            sim.run_from_ratings(1000, drivers, ratings, feats, {}, case['base_pace'], case['tire_deg'],
+                                 case['driver_variance'], case['driver_dnf_rates'], seed=1)
+        assert e.value.code == -1
+    # and the same call with finite inputs still runs
+    probs, _ = sim.run_from_ratings(1000, drivers, good, {}, {}, case['base_pace'], case['tire_deg'],
+                                    case['driver_variance'], case['driver_dnf_rates'], seed=1)
+    assert abs(sum(probs[drivers[0]].values()) - 1.0) < 1e-12

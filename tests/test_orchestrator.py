@@ -93,3 +93,35 @@ def test_weekend_glue_hands_the_same_arguments_to_the_hot_path(weekend, label):
     res = PR.pack_result(inp['drivers'], inp['grid_probs'], fake, inp['weather'], w['prediction_point'], w['actual_grid'])
     for k, v in w['result'].items():
         assert res[k] == v, k
+
+
+def test_calibration_curve_matches_reference(misc):
+    """calibration_analysis (reference src/validation.py:133-158, sklearn underneath) restated in numpy: the fixtures
+    hold the reference's own outputs for a season-sized sample, two small ones and the empty one."""
+    from monte_carlo_gp_amd.validation import calibration_analysis, calibration_curve
+    for name, c in misc['calibration'].items():
+        got = calibration_analysis(c['preds'], c['actuals'])
+        assert got == c['result'], name                        # same numpy operations in the same order: exact
+    with pytest.raises(ValueError):
+        calibration_curve([0, 1], [0.2, 1.5], n_bins=2)
+    with pytest.raises(ValueError):
+        calibration_curve([0, 2], [0.2, 0.5], n_bins=2)
+    assert calibration_analysis([{'win_probabilities': {'A': 2.0}}], [{'winner': 'A'}]) == {'prob_true': [], 'prob_pred': []}
+
+
+def test_known_pairs_update_equals_the_reference_on_a_complete_ordering(misc):
+    """cli._update_known_pairs (the sweep's Elo step, from outcome fixtures that only know pole / podium) restricted to
+    NO restriction -- every pair known -- is the reference's all-pairs update (src/elo.py:45-122)."""
+    from monte_carlo_gp_amd.cli import _update_known_pairs
+    from monte_carlo_gp_amd.elo import F1EloSystem
+    fx = misc['elo_full_order']
+    drivers = misc['drivers']
+    e = F1EloSystem()
+    for i, d in enumerate(drivers):
+        e.ratings[d] = {'quali': 1700.0 - 20.0 * i, 'race': 1650.0 - 15.0 * i}
+    e.set_recency_weight(0, fx['race_index'], fx['total'])
+    _update_known_pairs(e, 'quali', drivers, fx['order'])
+    _update_known_pairs(e, 'race', drivers, fx['order'])
+    for d in drivers:
+        for k in ('quali', 'race'):
+            assert abs(e.ratings[d][k] - fx['after'][d][k]) < 1e-9, (d, k)
