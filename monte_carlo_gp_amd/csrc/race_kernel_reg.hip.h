@@ -95,11 +95,13 @@ __host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
            (size_t)((kNumCompounds - 1) * kMaxCars + n) * 16 + kCompStride * 16 + 64 + 128 + align16((size_t)n * n * 4) +
            (size_t)n * n * 8;
 }
-// Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this).
+// Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this), chosen by measurement
+// (one box, 10^7 simulations): N = 10 39.0 ms at 4 waves, 40.7 at 3, 59.1 at 5; N = 20 100.3 at 3 against 118 at 2;
+// N = 21 112.7 at 2, 116.8 at 3 (the 168-register budget starts to spill); N = 25 139 at 2, 185 at 3.
 #ifdef MCGP_MIN_WAVES
 __host__ __device__ constexpr int reg_min_waves(int) { return MCGP_MIN_WAVES; }
 #else
-__host__ __device__ constexpr int reg_min_waves(int n) { return n <= 10 ? 4 : n <= 21 ? 3 : 2; }
+__host__ __device__ constexpr int reg_min_waves(int n) { return n <= 10 ? 4 : n <= 20 ? 3 : 2; }
 #endif
 // Waves per block: the (waves per block, blocks per CU) pair that keeps the most waves resident within the
 // LDS budget and the kernel's waves per SIMD; among equals at least 4 waves per block (fewer copies of the

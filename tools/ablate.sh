@@ -4,10 +4,12 @@
 #   tools/ablate.sh run     (on the GPU box, via gpurun)                    -> gpurun_out/ablate.txt
 # VARIANTS are -DMCGP_<name>=<value> switches of race_kernel_reg.hip.h:
 #   DUP=k   run section k twice (idempotent, results unchanged): its cost shows as a time difference
+#           (1 sorting network after the lap step, 4 _update_positions, 8 re-sort after an overtake pass, 16 event Philox block)
 #   SKIP=k  leave section k out (results wrong): timing only
+#           (1 overtake passes, 2 event handling, 4 grid sampling, 8 laps 2..L, 16 sorting network, 32 _update_positions, 64 lap step)
 set -e
 cd "$(dirname "$0")/.."
-VARIANTS=${VARIANTS:-"DUP=0 DUP=1 DUP=2 DUP=4 DUP=8 SKIP=1 SKIP=2 SKIP=4 SKIP=8"}
+VARIANTS=${VARIANTS:-"DUP=0 DUP=1 DUP=4 DUP=8 DUP=16 SKIP=1 SKIP=2 SKIP=4 SKIP=8 SKIP=16 SKIP=32 SKIP=64"}
 case "$1" in
 build)
   mkdir -p abl
