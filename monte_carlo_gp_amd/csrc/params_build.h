@@ -45,6 +45,7 @@ inline int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const d
     kp->pop_mh = cfg->pop_medium_hard;
     kp->pit_loss = cfg->pit_loss;
     kp->overtake_delta = cfg->overtake_delta;
+    kp->overtake_delta_31 = cfg->overtake_delta * 2147483648.0;
     kp->drs_delta = cfg->drs_delta;
     kp->dirty_thr = cfg->dirty_air_threshold;
     kp->dirty_pen = cfg->dirty_air_penalty;

@@ -29,6 +29,7 @@ constexpr uint32_t kDirty = 1u << 25;          // 0 < time_behind_leader < dirty
 struct KParams {
     int32_t n, total_laps, track, pop_sh, pop_mh, pad0;
     double pit_loss, overtake_delta, drs_delta, dirty_thr, dirty_pen;
+    double overtake_delta_31;       // overtake_delta x 2^31 (exact): the register kernel's pace deltas carry that scale
     // u < p  <=>  w < ceil(p * 2^32) for the 32-bit uniform u = w / 2^32
     uint64_t t_red, t_sc, t_vsc, t_vsc_tire;
     double comp_deg[kCompStride], comp_delta[kCompStride];

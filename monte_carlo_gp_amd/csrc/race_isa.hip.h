@@ -336,6 +336,9 @@ __device__ __forceinline__ double bpermute_f64(double x, int src_lane)   // src_
 // select and turn the select into a branch (no instruction is emitted).
 __device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+// a wave-uniform pointer the optimiser cannot see through: loads through it stay where they are written
+template <typename T>
+__device__ __forceinline__ void pin_ptr(const T *&p) { asm volatile("" : "+s"(p)); }
 
 // address of the dynamic LDS block as the hardware sees it
 __device__ __forceinline__ uint32_t lds_base_of(const void *p)

@@ -503,12 +503,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     auto grid_byte = [&](int pos) -> uint32_t { return G::oW + (uint32_t)(pos >> 2) * (B * 4) + tid4 + (uint32_t)(pos & 3); };
     auto norm_row = [&](uint32_t row) -> float4 { return lds_ld_float4(G::oNorm + row * 16u); };
 
-    const double pit_loss = P->pit_loss;
-    const double od31 = P->overtake_delta * 2147483648.0;      // overtake_delta x 2^31 (exact), see reg_load_tables
-    const double dirty_thr = P->dirty_thr;
-    const double dirty_pen = P->dirty_pen;
+    const double dirty_thr = P->dirty_thr;                     // (lap 1; the lap loop reads its constants per lap)
     const float kNaN = __uint_as_float(0x7fc00000u);
-    const uint64_t t_red = P->t_red, t_sc = P->t_sc, t_vsc = P->t_vsc, t_vsc_tire = P->t_vsc_tire;
 
     // Everything the lap step of one slot reads from LDS.
     struct SlotIn {
@@ -686,6 +682,13 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             uint32_t c0l = c0, c1l = c1;
             pin(c0l);
             pin(c1l);
+            // The per-race constants of the lap body are read from the parameter block EVERY lap (scalar loads through
+            // a pointer the optimiser cannot see through) instead of being held in registers across the whole race:
+            // eight 64-bit values that would otherwise push as many lane masks and addresses out to scratch.
+            const KParams *Pl = P;
+            pin_ptr(Pl);
+            const double pit_loss = Pl->pit_loss, od31 = Pl->overtake_delta_31, dirty_thr = Pl->dirty_thr, dirty_pen = Pl->dirty_pen;
+            const uint64_t t_red = Pl->t_red, t_sc = Pl->t_sc, t_vsc = Pl->t_vsc, t_vsc_tire = Pl->t_vsc_tire;
             // ---- race-interrupting events, :168-176 ----
             {
                 uint32_t e0, e1, e2, e3;
@@ -712,8 +715,13 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     constexpr int kRowsPerField = (12 * N <= 256) ? 1 : 2;      // cum (8 N bytes) and pk (4 N) of one field
                     constexpr int kFields = kWordRows / kRowsPerField;          // fields parked at a time
                     constexpr uint32_t oPk = kRowsPerField == 1 ? 8u * N : (uint32_t)(B * 4);
-                    const uint32_t lane = tid & 63u;
-                    const uint32_t wbase = G::oW + (tid4 & ~255u);              // this wave's 256-byte window of row 0
+                    // (lane number, lane masks and window address are worked out HERE, from a thread index the optimiser
+                    //  cannot trace back: hoisted out of the race they would sit in registers -- in scratch, as it turned
+                    //  out -- for all of it)
+                    uint32_t tid_e = tid;
+                    pin(tid_e);
+                    const uint32_t lane = tid_e & 63u;
+                    const uint32_t wbase = G::oW + ((tid_e * 4u) & ~255u);      // this wave's 256-byte window of row 0
                     const bool dec_age = sc || (vsc && (uint64_t)e3 < t_vsc_tire);
                     const uint32_t flags = (red ? 1u : 0u) | (vsc ? 4u : 0u) | (dec_age ? 8u : 0u);
                     const uint32_t newc = stint_compound(track, remaining_laps);
@@ -918,7 +926,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             // ---- _simulate_overtakes, :496-536 ----
             if (!(MCGP_SKIP & 16)) network_sort<N>(cum, pk);
             if (MCGP_DUP & 1) network_sort<N>(cum, pk);
-#pragma unroll 1
+            // The three passes are three copies of the code: a rolled loop makes the compiler shuffle the whole field
+            // (60 registers, renamed by every compare-exchange) back into place at its back edge; unrolled it is 3-4 %
+            // faster at every field size although the lap body no longer fits a 64 KB instruction cache.
+#pragma unroll
             for (int pass = 0; pass < ((MCGP_SKIP & 1) ? 0 : 3); ++pass) {
                 // ---- overtakes: pace deltas and candidates ----
                 // pace of every slot (:514-515), the pace delta of every adjacent pair, and what an attempt needs to

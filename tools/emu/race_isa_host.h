@@ -102,6 +102,8 @@ inline bool lt_u64(uint32_t w, uint32_t lo, uint32_t hi) { return (uint64_t)w < 
 #endif
 inline void pin(uint32_t &) {}
 inline void pin(double &) {}
+template <typename T>
+inline void pin_ptr(const T *&) {}
 inline float4 lds_ld_float4(uint32_t addr) { return lds_ld<float4>(addr); }
 inline uint32_t lds_base_of(const void *p) { return (uint32_t)((const unsigned char *)p - smem); }
 }  // namespace mcgp
