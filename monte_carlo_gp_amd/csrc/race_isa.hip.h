@@ -302,11 +302,6 @@ __device__ __forceinline__ uint32_t cvt_u32_f64_sat(double x)
 }
 __device__ __forceinline__ double ceil_f64(double x) { return __builtin_ceil(x); }
 __device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-// w < (hi << 32 | lo) for a 32-bit w: one 64-bit compare
-__device__ __forceinline__ bool lt_u64(uint32_t w, uint32_t lo, uint32_t hi)
-{
-    return (uint64_t)w < (((uint64_t)hi << 32) | (uint64_t)lo);
-}
 // scheduling fence: the compiler's instruction scheduler moves nothing across it
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // ---- cross-lane pieces of the cooperative event handler ----

@@ -91,7 +91,6 @@ inline uint32_t cvt_u32_f64_sat(double x)
 inline void sched_fence() {}
 inline double ceil_f64(double x) { return std::ceil(x); }
 inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-inline bool lt_u64(uint32_t w, uint32_t lo, uint32_t hi) { return (uint64_t)w < (((uint64_t)hi << 32) | (uint64_t)lo); }
 // threads of the emulated block run one after another: "any lane" is this thread alone (both paths behind an
 // MCGP_ANY test compute the same results, so which one a thread takes does not matter); EMU_FORCE_ANY=1 sends every
 // thread down the "some lane needs it" path, which a single-thread view would otherwise reach only rarely
