@@ -282,6 +282,28 @@ __device__ __forceinline__ f64x2 lds_ld_f64x2(uint32_t addr)             // one 
     const v2d v = *reinterpret_cast<const MCGP_LDS v2d *>(addr);
     return f64x2{v.x, v.y};
 }
+// 16-byte stores / loads of two doubles or four words (16-byte aligned address)
+__device__ __forceinline__ void lds_st_f64x2(uint32_t addr, double a, double b)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d v;
+    v.x = a;
+    v.y = b;
+    *reinterpret_cast<MCGP_LDS v2d *>(addr) = v;
+}
+__device__ __forceinline__ void lds_st_u32x4(uint32_t addr, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    v4u v;
+    v.x = a; v.y = b; v.z = c; v.w = d;
+    *reinterpret_cast<MCGP_LDS v4u *>(addr) = v;
+}
+__device__ __forceinline__ void lds_ld_u32x4(uint32_t addr, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = *reinterpret_cast<const MCGP_LDS v4u *>(addr);
+    a = v.x; b = v.y; c = v.z; d = v.w;
+}
 // {f64, u32, u32}: one ds_read_b128 (16-byte aligned address)
 __device__ __forceinline__ void lds_ld_f64_u32x2(uint32_t addr, double &d, uint32_t &u0, uint32_t &u1)
 {

@@ -712,9 +712,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const bool evt = !(MCGP_SKIP & 2) && (red || sc || vsc);
                 const unsigned long long emask = __ballot(evt);
                 if (emask != 0ull) {
-                    constexpr int kRowsPerField = (12 * N <= 256) ? 1 : 2;      // cum (8 N bytes) and pk (4 N) of one field
+                    constexpr int kRowsPerField = (align16(8 * N) + 4 * N <= 256) ? 1 : 2;   // cum (8 N bytes) and pk (4 N) of one field
                     constexpr int kFields = kWordRows / kRowsPerField;          // fields parked at a time
-                    constexpr uint32_t oPk = kRowsPerField == 1 ? 8u * N : (uint32_t)(B * 4);
+                    constexpr uint32_t oPk = kRowsPerField == 1 ? (uint32_t)align16(8 * N) : (uint32_t)(B * 4);   // 16-byte aligned
                     // (lane number, lane masks and window address are worked out HERE, from a thread index the optimiser
                     //  cannot trace back: hoisted out of the race they would sit in registers -- in scratch, as it turned
                     //  out -- for all of it)
@@ -734,12 +734,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const unsigned long long cur = todo & ~rest;
                         const bool mine = evt && ((cur >> lane) & 1ull);
                         const uint32_t my_base = wbase + (uint32_t)__popcll(cur & ((1ull << lane) - 1ull)) * (uint32_t)(kRowsPerField * B * 4);
-                        if (mine) {
+                        if (mine) {                                         // park: two times / four pk words per store
 #pragma unroll
-                            for (int i = 0; i < N; ++i) {
-                                lds_st<double>(my_base + 8u * i, cum[i]);
-                                lds_st<uint32_t>(my_base + oPk + 4u * i, pk[i]);
-                            }
+                            for (int i = 0; i + 1 < N; i += 2) lds_st_f64x2(my_base + 8u * i, cum[i], cum[i + 1]);
+                            if (N & 1) lds_st<double>(my_base + 8u * (N - 1), cum[N - 1]);
+#pragma unroll
+                            for (int i = 0; i + 3 < N; i += 4) lds_st_u32x4(my_base + oPk + 4u * i, pk[i], pk[i + 1], pk[i + 2], pk[i + 3]);
+#pragma unroll
+                            for (int i = N & ~3; i < N; ++i) lds_st<uint32_t>(my_base + oPk + 4u * i, pk[i]);
                         }
                         wave_sync();
                         uint32_t field = 0u;
@@ -781,12 +783,18 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                             if (__ballot(tie_here) != 0ull) tiemask |= 1ull << L;
                         }
                         wave_sync();
-                        if (mine) {
+                        if (mine) {                                         // take the field back
 #pragma unroll
-                            for (int i = 0; i < N; ++i) {
-                                cum[i] = lds_ld<double>(my_base + 8u * i);
-                                pk[i] = lds_ld<uint32_t>(my_base + oPk + 4u * i);
+                            for (int i = 0; i + 1 < N; i += 2) {
+                                const f64x2 v = lds_ld_f64x2(my_base + 8u * i);
+                                cum[i] = v.x;
+                                cum[i + 1] = v.y;
                             }
+                            if (N & 1) cum[N - 1] = lds_ld<double>(my_base + 8u * (N - 1));
+#pragma unroll
+                            for (int i = 0; i + 3 < N; i += 4) lds_ld_u32x4(my_base + oPk + 4u * i, pk[i], pk[i + 1], pk[i + 2], pk[i + 3]);
+#pragma unroll
+                            for (int i = N & ~3; i < N; ++i) pk[i] = lds_ld<uint32_t>(my_base + oPk + 4u * i);
                         }
                         wave_sync();                                        // before the next batch of fields reuses the window
                         todo = rest;
