@@ -909,7 +909,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const double noise = 0.0 + s.var * (double)z[j];                            // :330
                         const double clean = s.base + tire - fuel_effect + s.cdelta - drs_gain + noise;   // :332
                         const double dirty_time = clean + dirty_pen;                                // :213
-                        const double held = ahead_last > dirty_time ? ahead_last : dirty_time;       // :215
+                        const double held = max_f64(ahead_last, dirty_time);                        // :215 (neither is NaN)
                         const bool in_dirty = (p & k3Dirty) && ahead_last > 0;                      // :209-212
                         const double lap_time = in_dirty ? held : clean;
                         // pit stop (:450-492): (tyre age + 1) << 16 against the pit word; compound and used-set from

@@ -7,7 +7,7 @@ Mirrors the reference's interface for the hot path (reference src/simulation.py)
     RaceSimulator.run_monte_carlo(...)           :59-100  same arguments, same result shape
     RaceSimulator.simulate_race(grid, ...)       :147-242 one race, list of (driver, position)
 
-The per-lap loop itself runs in hand-written HIP (csrc/race_kernel.hip.h) behind
+The per-lap loop itself runs in hand-written HIP (csrc/race_kernel_reg.hip.h) behind
 the C ABI of include/mcgp.h; this module only resolves the reference's dict
 defaults into dense arrays, calls the library through ctypes and reshapes the
 integer histogram into the reference's `dict[driver][position] -> probability`.
@@ -35,7 +35,8 @@ from . import _native as N
 class CarState:
     """Per-car state of one simulation (reference :9-34); kept for interface parity.
 
-    On the device this is a structure-of-arrays row set in LDS, see csrc/race_kernel.hip.h.
+    On the device a car is a slot of two register arrays (time, packed state word) of its simulation's lane,
+    see csrc/race_kernel_reg.hip.h.
     """
     driver: str
     team: str

@@ -5,7 +5,7 @@
 
 Every machine instruction of the listing is attributed to the source line of its .loc; lines of
 race_kernel_reg.hip.h are grouped by the `// @region name` markers found in that file (helpers above the
-kernel are grouped by function).  Counts are STATIC: rolled loops (RNG pre-pass, overtake pass loop) count once.
+kernel are grouped by function).  Counts are STATIC: rolled loops (grid sampling, lap 1 draws, the rare general paths) count once; the three overtake passes are three copies.
 Not product code.
 """
 import collections
