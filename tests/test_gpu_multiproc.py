@@ -183,3 +183,8 @@ def test_bench_through_rccl_world1(tmp_path):
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
     assert d['n_gpus'] == 1 and d['process_group'] == 'nccl' and d['value'] > 0
     assert abs(d['win_probability_top3']['VER'] - 0.5445) < 0.005
+    # the roofline block names the binding resource and keeps the nominal HBM figure beside it
+    roof = d['roofline']
+    assert roof['bound'] == 'valu-issue' and roof['kernel'] == 'mcgp::race_kernel_reg<20>' and roof['kernel_ms_avg'] > 0
+    assert roof['hbm_nominal']['bound'] == 'hbm' and 0 < roof['hbm_nominal']['frac'] < 1e-3
+    assert (roof['frac'] is None) == (roof['counters_note'] is not None)      # counters quoted, or the reason why not

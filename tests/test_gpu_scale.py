@@ -147,3 +147,30 @@ def test_configs3_one_billion_simulations_as_eight_shards(require_gpu):
     # and the first 1e8 of the big run are those simulations: ranks 0..7 of 1e9 cover [0, 1e9) contiguously, so the
     # 1e8 histogram must be dominated cell by cell by the 1e9 one
     assert (a <= hist).all()
+
+
+def _oracle_hist_all_cores(case, n_sims, seed, threads=16, chunk=50_000):
+    """The oracle's histogram of simulations [0, n_sims), chunks spread over host threads (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(case['grid_probs'])
+    offsets = list(range(0, n_sims, chunk))
+    problems = [O.Problem(case) for _ in range(threads)]
+
+    def work(k):
+        h = np.zeros((n, n), np.int64)
+        for off in offsets[k::threads]:
+            h += problems[k].run(min(chunk, n_sims - off), rng=O.RNG_PHILOX, seed=seed, sim_offset=off)['hist']
+        return h
+    with ThreadPoolExecutor(threads) as ex:
+        return sum(ex.map(work, range(threads)))
+
+
+@pytest.mark.parametrize('name,n_sims', [('S60', 10_000_000), ('S78', 3_000_000)])
+def test_full_size_histogram_equals_the_oracle(require_gpu, name, n_sims):
+    """BASELINE configs[1] at its full size, not through a property: the integer driver x position histogram of 10^7
+    simulations (seed 42) from the GPU equals the CPU oracle's, cell for cell (about a minute of oracle time on the
+    host cores of the GPU box); the Monaco configuration at 3 x 10^6."""
+    case = O.load_case(name)
+    hist, _, _ = product_run(case, n_sims, 42)
+    ref = _oracle_hist_all_cores(case, n_sims, 42)
+    assert np.array_equal(hist, ref), int(np.abs(hist - ref).sum())
