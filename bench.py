@@ -17,7 +17,8 @@ The JSON line printed by rank 0 carries, besides the contract fields,
   roofline       the BINDING resource, VALU instruction issue: wave-level VALU instructions per launch (PMC) / live
                  kernel time (hipEvents on the launch stream) against 1024 SIMDs x 2.4 GHz / 2 cycles (the guide's
                  SIMD-32 rate; `frac`), and against the 4-cycle rate that the datasheet's 78.6 TFLOP/s of vector FP64
-                 implies (`frac_at_fp64_rate`), with the PMC's own VALUBusy beside them; `traffic` = HBM bytes per
+                 implies (`frac_at_fp64_rate`), and against the ceiling of the kernel's own instruction mix with issue
+                 costs measured per class (`frac_of_mix_ceiling`), with the PMC's own VALUBusy beside them; `traffic` = HBM bytes per
                  launch from the PMC passes; roofline.hbm_nominal = the 20 algorithmic bytes per simulation
                  against the 8 TB/s HBM peak -- evidence that the path is NOT memory bound.  Counters are quoted only
                  when profiles/r3_counters.json carries the source hash of the loaded library (else null, reason in
@@ -319,6 +320,19 @@ def main():
                          'scratch_bytes_per_lane': int(pc.get('kernel', {}).get('Scratch_Size', 0) or 0),
                          'source_hash': pc.get('source_hash'),
                          'counters': 'profiles/r3_counters.json (rocprofv3 --pmc, tools/profile_r3.sh), same source hash as the loaded library'})
+            # the ceiling for THIS kernel's instruction mix: measured issue cost per class (tools/valu_peak.hip: binary64
+            # and VOP3 / 64-bit integer instructions ~4.2 cycles per wave64 instruction, VOP1 / VOP2 32-bit ones ~2.25)
+            # weighted by the class shares of the lap loop (tools/valu_mix.py), same source hash
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r3_valu_mix.json')) as f:
+                    mix = json.load(f)
+                if mix.get('source_hash') == pc.get('source_hash'):
+                    roof.update({'peak_for_instruction_mix': mix['peak_T_wave_instructions_per_s_for_this_mix'],
+                                 'frac_of_mix_ceiling': rate / mix['peak_T_wave_instructions_per_s_for_this_mix'],
+                                 'share_four_cycle_class': mix['share_four_cycle'],
+                                 'mean_cycles_per_instruction_for_mix': mix['mean_cycles_per_instruction_for_this_mix']})
+            except (OSError, ValueError, KeyError):
+                pass
         roof.update({
             'kernel': r['kernel'], 'kernel_ms_avg': kavg_ms, 'counters_note': why_not,
             'peak_note': 'peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: SIMD-32); '
