@@ -491,7 +491,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 
     // ---- typed views of the LDS map (RegGeo) for the cold paths (grid sampling, histogram) ----
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + G::oHist);
-    double *t_grid = reinterpret_cast<double *>(smem + G::oGrid);          // [slot][driver]
 
     // per-lane rows by ABSOLUTE LDS address (race_isa.hip.h): a compile-time row is an immediate offset ...
     auto w_row = [&](int r) -> uint32_t { return G::oW + (uint32_t)r * (B * 4) + tid4; };
@@ -542,7 +541,11 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         double cum[N];
         uint32_t pk[N];
 
-        // ================= _sample_grid, reference :102-145 (probs scratch in the LAST rows) =================
+        // ================= _sample_grid, reference :102-145 =================
+        // One grid slot per iteration, all N drivers in straight-line code (like the reference's list comprehensions,
+        // which also run over every driver with zeros for the placed ones: adding +0.0 changes no sum, and a placed
+        // driver's cdf entry repeats its predecessor's, so it is never the first one above u).  The column of the
+        // grid matrix is the same for every lane: N wave-uniform LDS reads; everything else stays in registers.
         {
             uint32_t remaining = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
             int n_remaining = N;
@@ -560,27 +563,33 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         philox4x32_10(c0, c1, 0u, kPurposeGrid | (uint32_t)(pos >> 2), seed_lo, seed_hi, g0, g1, g2, g3);
                     const uint32_t gw = (pos & 3) == 0 ? g0 : (pos & 3) == 1 ? g1 : (pos & 3) == 2 ? g2 : g3;
                     const double u = u32_to_unit(gw);
-                    // Only the drivers still unplaced contribute (zeros add nothing to the sums and repeat
-                    // the running cdf), so each pass walks the `remaining` bit set: N - pos steps on every lane.
-                    const double *gcol = t_grid + pos * N;
-                    double total = 0.0;                                   // :119-123
-                    for (uint32_t m = remaining; m; m &= m - 1u) total = total + gcol[__ffs((int)m) - 1];
-                    double prob_sum = 0.0;                                // :125-133
-                    for (uint32_t m = remaining; m; m &= m - 1u) {
-                        const int d = __ffs((int)m) - 1;
-                        const double p = total > 0 ? gcol[d] / total : 1.0 / (double)n_remaining;
-                        lds_st<double>(l_row(d), p);
-                        prob_sum = prob_sum + p;
+                    const uint32_t gcol = G::oGrid + (uint32_t)(pos * N) * 8u;           // [slot][driver], wave-uniform
+                    double p[N];
+                    double total = 0.0;                                                  // :119-123
+#pragma unroll
+                    for (int d = 0; d < N; ++d) {
+                        p[d] = ((remaining >> d) & 1u) ? lds_ld<double>(gcol + 8u * d) : 0.0;
+                        total = total + p[d];
                     }
-                    const bool renorm = prob_sum > 0 && fabs(prob_sum - 1.0) > 1e-9;   // :134-135
+                    const bool has_mass = total > 0;
+                    const double uniform_p = 1.0 / (double)n_remaining;                  // :127-130
+                    double prob_sum = 0.0;                                               // :125-133
+#pragma unroll
+                    for (int d = 0; d < N; ++d) {
+                        const double q = has_mass ? p[d] / total : uniform_p;
+                        p[d] = ((remaining >> d) & 1u) ? q : 0.0;
+                        prob_sum = prob_sum + p[d];
+                    }
+                    if (prob_sum > 0 && fabs(prob_sum - 1.0) > 1e-9) {                   // :134-135 (practically never)
+#pragma unroll
+                        for (int d = 0; d < N; ++d) p[d] = p[d] / prob_sum;
+                    }
                     // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right')
                     double acc = 0.0;
-                    for (uint32_t m = remaining; m; m &= m - 1u) {
-                        const int d = __ffs((int)m) - 1;
-                        double p = lds_ld<double>(l_row(d));
-                        if (renorm) p = p / prob_sum;
-                        acc = acc + p;
-                        lds_st<double>(l_row(d), acc);
+#pragma unroll
+                    for (int d = 0; d < N; ++d) {
+                        acc = acc + p[d];
+                        p[d] = acc;
                     }
                     const double cdf_last = acc;
                     // searchsorted(cdf / cdf[-1], u, 'right'): the first driver with cdf[d] / cdf_last > u.  The
@@ -590,17 +599,18 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     // instructions on this hardware -- runs only for a cdf entry within 2^-49 of the threshold.
                     const double uc = u * cdf_last;
                     const double sure_le = uc * (1.0 - 0x1p-50), sure_gt = uc * (1.0 + 0x1p-50);
-                    sel = (uint32_t)N;
-                    for (uint32_t m = remaining; m; m &= m - 1u) {        // first driver whose cdf exceeds u
-                        const int d = __ffs((int)m) - 1;
-                        const double x = lds_ld<double>(l_row(d));
-                        bool exceeds;
-                        if (x <= sure_le) exceeds = false;
-                        else if (x >= sure_gt) exceeds = true;
-                        else exceeds = !(x / cdf_last <= u);
-                        if (sel == (uint32_t)N && exceeds) sel = (uint32_t)d;
+                    uint32_t above = 0u, unsure = 0u;                                    // bit d: cdf[d] / cdf_last > u / not certain
+#pragma unroll
+                    for (int d = 0; d < N; ++d) {
+                        above |= p[d] >= sure_gt ? (1u << d) : 0u;
+                        unsure |= (p[d] > sure_le && !(p[d] >= sure_gt)) ? (1u << d) : 0u;
                     }
-                    if (sel >= (uint32_t)N) sel = 31u - (uint32_t)__clz((int)remaining);   // unreachable: cdf[-1] == 1 > u
+                    if (unsure != 0u) {
+#pragma unroll
+                        for (int d = 0; d < N; ++d)
+                            if ((unsure >> d) & 1u) above |= !(p[d] / cdf_last <= u) ? (1u << d) : 0u;
+                    }
+                    sel = above ? (uint32_t)__ffs((int)above) - 1u : 31u - (uint32_t)__clz((int)remaining);   // (never empty: cdf[-1] == 1 > u)
                 }
                 if ((remaining >> sel) & 1u) { remaining &= ~(1u << sel); --n_remaining; }
                 lds_st<uint8_t>(grid_byte(pos), (uint8_t)sel);
@@ -707,8 +717,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // wave-laps have one in SOME lane, and a handler run by every lane for the sake of ~2 of them was a
                 // tenth of the kernel.  So the wave turns the problem round: a lane with an event parks its field in
                 // the wave's window of the W plane (free outside the overtake passes), the wave handles one such field
-                // at a time with LANE = CAR -- the leader is a ballot + readlane, a car's place among the running cars
-                // a mbcnt, the neighbour's new time a bpermute -- and the lane takes its field back.
+                // (two, in fact: one per half of the wave) at a time with LANE = CAR -- the leader is a ballot + readlane,
+                // a car's place among the running cars a popcount of the ballot below it, the neighbour's new time a
+                // bpermute -- and the lane takes its field back.
                 const bool evt = !(MCGP_SKIP & 2) && (red || sc || vsc);
                 const unsigned long long emask = __ballot(evt);
                 if (emask != 0ull) {
@@ -744,43 +755,55 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                             for (int i = N & ~3; i < N; ++i) lds_st<uint32_t>(my_base + oPk + 4u * i, pk[i]);
                         }
                         wave_sync();
+                        // two parked fields at a time: lanes 0..31 are the cars of one, lanes 32..63 of the next
                         uint32_t field = 0u;
-                        for (unsigned long long mm = cur; mm != 0ull; mm &= mm - 1ull, ++field) {
-                            const int L = __ffsll((long long)mm) - 1;                               // the lane whose field this is
-                            const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)flags, L);
+                        for (unsigned long long mm = cur; mm != 0ull; field += 2u) {
+                            const int LA = __ffsll((long long)mm) - 1;                              // the lanes whose fields these are
+                            mm &= mm - 1ull;
+                            const bool two = mm != 0ull;
+                            const int LB = two ? __ffsll((long long)mm) - 1 : LA;
+                            mm &= mm - 1ull;
+                            const uint32_t half = lane >> 5, car = lane & 31u;
+                            const uint32_t flA = (uint32_t)__builtin_amdgcn_readlane((int)flags, LA);
+                            const uint32_t flB = (uint32_t)__builtin_amdgcn_readlane((int)flags, LB);
+                            const uint32_t fl = half ? flB : flA;
                             const bool red_L = fl & 1u, vsc_L = fl & 4u;
                             const uint32_t dec_unit = (fl & 8u) ? (1u << k3AgeShift) : 0u;
                             const double step = red_L ? 0.1 : 0.5;
-                            const uint32_t base = wbase + field * (uint32_t)(kRowsPerField * B * 4);
+                            const uint32_t base = wbase + (field + half) * (uint32_t)(kRowsPerField * B * 4);
                             bool tie_here = false;
-                            if (lane < (uint32_t)N) {
-                                const double t = lds_ld<double>(base + 8u * lane);
-                                const uint32_t p = lds_ld<uint32_t>(base + oPk + 4u * lane);
+                            if (car < (uint32_t)N && (half == 0u || two)) {
+                                const double t = lds_ld<double>(base + 8u * car);
+                                const uint32_t p = lds_ld<uint32_t>(base + oPk + 4u * car);
                                 const bool act = !(p & k3Dnf);
-                                const unsigned long long am = __ballot(act);                         // the running cars
-                                if (am != 0ull) {
-                                    const double leader = readlane_f64(t, __ffsll((long long)am) - 1);
-                                    const unsigned long long below = am & ((1ull << lane) - 1ull);   // running cars ahead of this one
-                                    const double kd = (double)__popcll(below);
-                                    const double nt_fixed = leader + kd * step;                      // :363 / :412
-                                    const double gap = t - leader;
-                                    const double nt_vsc = leader + gap * 0.8;                        // :386-387
-                                    const double nt = vsc_L ? nt_vsc : nt_fixed;
-                                    // x0.8 may round two running cars onto one time: compare with the running car ahead
-                                    const double pn = bpermute_f64(nt, below ? 63 - __clzll((long long)below) : 0);
-                                    tie_here = act && below != 0ull && pn == nt;
-                                    const double tbl = nt - leader;                                  // :371 / :388 / :413
-                                    uint32_t q = (p & ~k3Dirty) | ((tbl > 0 && tbl < dirty_thr) ? k3Dirty : 0u);
-                                    const uint32_t agef = q & k3AgeMask;
-                                    q -= agef < dec_unit ? agef : dec_unit;                          // max(0, tire_age - 1), :375 / :393-395
-                                    const uint32_t q_red = (q & ~(k3CompMask | k3AgeMask)) | red_bits;   // :414-429
-                                    q = red_L ? q_red : q;
-                                    lds_st<double>(base + 8u * lane, act ? nt : t);
-                                    lds_st<uint32_t>(base + oPk + 4u * lane, act ? q : p);
-                                }
+                                const unsigned long long am2 = __ballot(act);                        // the running cars of both fields
+                                const uint32_t amA = (uint32_t)am2, amB = (uint32_t)(am2 >> 32);
+                                // (a field without a running car: nothing below is committed for it)
+                                const double leadA = readlane_f64(t, amA ? __ffs((int)amA) - 1 : 0);
+                                const double leadB = readlane_f64(t, amB ? 32 + __ffs((int)amB) - 1 : 32);
+                                const double leader = half ? leadB : leadA;
+                                const uint32_t below = (half ? amB : amA) & ((1u << car) - 1u);     // running cars ahead of this one
+                                const double kd = (double)__popc(below);
+                                const double nt_fixed = leader + kd * step;                          // :363 / :412
+                                const double gap = t - leader;
+                                const double nt_vsc = leader + gap * 0.8;                            // :386-387
+                                const double nt = vsc_L ? nt_vsc : nt_fixed;
+                                // x0.8 may round two running cars onto one time: compare with the running car ahead
+                                const double pn = bpermute_f64(nt, (int)(half * 32u) + (below ? 31 - __clz((int)below) : 0));
+                                tie_here = act && below != 0u && pn == nt;
+                                const double tbl = nt - leader;                                      // :371 / :388 / :413
+                                uint32_t q = (p & ~k3Dirty) | ((tbl > 0 && tbl < dirty_thr) ? k3Dirty : 0u);
+                                const uint32_t agef = q & k3AgeMask;
+                                q -= agef < dec_unit ? agef : dec_unit;                              // max(0, tire_age - 1), :375 / :393-395
+                                const uint32_t q_red = (q & ~(k3CompMask | k3AgeMask)) | red_bits;   // :414-429
+                                q = red_L ? q_red : q;
+                                lds_st<double>(base + 8u * car, act ? nt : t);
+                                lds_st<uint32_t>(base + oPk + 4u * car, act ? q : p);
                             }
-                            // (every lane of the wave records the verdict: the lane whose field this is may not be a car lane)
-                            if (__ballot(tie_here) != 0ull) tiemask |= 1ull << L;
+                            // (every lane of the wave records the verdicts: the lanes whose fields these are may not be car lanes)
+                            const unsigned long long ties = __ballot(tie_here);
+                            if ((uint32_t)ties != 0u) tiemask |= 1ull << LA;
+                            if ((uint32_t)(ties >> 32) != 0u) tiemask |= 1ull << LB;
                         }
                         wave_sync();
                         if (mine) {                                         // take the field back
