@@ -390,7 +390,10 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     for (uint64_t done = 0; done < n_sims; done += cap) {
         const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
         launch_geometry(c, (uint32_t)kp.n, is_reg, kernel, m, &grid, &block, &lds);
-        const uint64_t n_batches = (m + block - 1) / block;             // < 2^32 because m < 2^32
+        // units of work: the register kernel's waves claim chunks of 64 simulations, a block of the generic kernel
+        // takes batches of `block` (both < 2^32 because m < 2^32)
+        const uint64_t unit = is_reg ? 64u : block;
+        const uint64_t n_batches = (m + unit - 1) / unit;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
                            (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
                            d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,

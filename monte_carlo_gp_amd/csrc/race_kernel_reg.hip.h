@@ -131,6 +131,7 @@ struct RegGeo {
     static constexpr uint32_t oIc = oDrvB + (kMaxCars + N) * 16;  // [compound][driver] {eff f64, pit word u32, DNF threshold u32}
     static constexpr uint32_t oComp = oIc + ((kNumCompounds - 1) * kMaxCars + N) * 16;   // {delta f64, pad} x 8, 16 B each
     static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}              (lap time)
+    static constexpr uint32_t oTicket = oDrs + 8;                 // u32 in the first pad: the block's next unclaimed wave-chunk
     static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, pad}, {drs_delta 2^31, pad}         (overtake pace)
     static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
     static constexpr uint32_t oHist = oLut + 128;                 // u32[N x N]
@@ -433,7 +434,7 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
     if (tid < 2) {
         double *r = reinterpret_cast<double *>(smem + G::oDrs + tid * 16);
         r[0] = tid ? P->drs_delta : 0.0;
-        r[1] = 0.0;
+        r[1] = 0.0;                                              // (tid 0: also the chunk ticket G::oTicket = 0)
         double *q = reinterpret_cast<double *>(smem + G::oDrsB + tid * 16);
         q[0] = tid ? P->drs_delta * 2147483648.0 : 0.0;
         q[1] = 0.0;
@@ -474,13 +475,17 @@ __device__ __forceinline__ void reg_flush_hist(unsigned char *smem, uint32_t tid
     }
 }
 
-// Phase 2: this lane's simulations (batches block_index, block_index + n_blocks, ...), one full race each.
+// Phase 2: the block's simulations, one full race per lane.  The unit of work is a WAVE-CHUNK of 64 consecutive
+// simulations; block b owns chunks b, b + n_blocks, ... and its waves claim them one at a time from a ticket in LDS,
+// so a wave that runs faster than its neighbours (an odd number of waves per SIMD does not share the VALU issue
+// slots evenly, tools/valu_peak.hip) takes more chunks instead of idling at the end.  Which wave runs a simulation
+// changes nothing in its result: every draw is addressed by the simulation's global id.
 template <int N>
 __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid,
                                              uint32_t block_index, uint32_t n_blocks, uint64_t n_sims,
                                              uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
                                              uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid,
-                                             uint32_t n_batches)
+                                             uint32_t n_chunks)
 {
     using G = RegGeo<N>;
     constexpr int B = G::B;
@@ -529,8 +534,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         return r;
     };
 
-    for (uint32_t batch = block_index; batch < n_batches; batch += n_blocks) {
-        const uint64_t local = (uint64_t)batch * (uint64_t)B + (uint64_t)tid;
+    for (uint32_t turn = 0u;; ++turn) {
+        const uint64_t chunk = (uint64_t)block_index + (uint64_t)next_ticket(G::oTicket, tid, turn, G::kWaves) * (uint64_t)n_blocks;
+        if (chunk >= (uint64_t)n_chunks) break;
+        const uint64_t local = chunk * 64ull + (uint64_t)(tid & 63u);
         // A lane past the end of the run still runs a race while any lane of its wave has one to run -- the wave's
         // lanes work for each other in the event handler (lane = car) -- but records nothing.
         const bool live = local < n_sims;
@@ -1152,7 +1159,7 @@ template <int N>
 __global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
-                uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
+                uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // host and kernel must agree on the geometry, and the rows are addressed by absolute LDS address
@@ -1161,7 +1168,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     reg_load_tables<N>(P, smem, threadIdx.x);
     __syncthreads();
     reg_simulate<N>(P, smem, threadIdx.x, blockIdx.x, gridDim.x, n_sims, sim_offset, seed_lo, seed_hi, orders,
-                    fixed_grid, n_batches);
+                    fixed_grid, n_chunks);
     __syncthreads();
     reg_flush_hist<N>(smem, threadIdx.x, hist);
 }

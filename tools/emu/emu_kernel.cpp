@@ -65,11 +65,11 @@ static int run_size(const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offse
     if constexpr (N % EMU_PARTS == EMU_PART) {
         // one block at a time; inside a block the three phases of the kernel run for every "thread" in turn
         constexpr uint32_t B = mcgp::RegGeo<N>::B;
-        const uint32_t n_batches = (uint32_t)((n_sims + B - 1) / B);
+        const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
         for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N>(&kp, mcgp::smem, t);
         for (uint32_t t = 0; t < B; ++t)
             mcgp::reg_simulate<N>(&kp, mcgp::smem, t, 0u, 1u, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32),
-                                  orders, fixed_grid, n_batches);
+                                  orders, fixed_grid, n_chunks);
         for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N>(mcgp::smem, t, hist);
         return 0;
     } else {
