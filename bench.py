@@ -54,10 +54,10 @@ COUNTERS_FILE = 'r3_counters.json'
 def load_workload(name):
     with open(os.path.join(ROOT, 'tests', 'golden', 'cases.json')) as f:
         meta = json.load(f)
-    if name == 'N25':
-        # 25-car field (no register instantiation: served by the generic LDS kernel), S60 parameters
+    if name not in meta['cases'] and name[:1] == 'N' and name[1:].isdigit():
+        # N<k>: a k-car field with S60's parameters (N25 is the profiled one; N22 is a 2026-sized grid)
         base = meta['cases']['S60']
-        drivers = [f'D{i:02d}' for i in range(25)]
+        drivers = [f'D{i:02d}' for i in range(int(name[1:]))]
         teams = list(base['config']['dnf_rates'])
         n = len(drivers)
         sigma = n / 4

@@ -112,6 +112,7 @@ struct DeviceCtx {
     struct Timer {
         hipStream_t stream = nullptr;
         hipEvent_t start = nullptr, stop = nullptr;
+        uint32_t *d_ticket = nullptr;       // the work counter of this stream's launches (race_kernel_reg.hip.h, phase 2)
         bool used = false;
         uint64_t seq = 0;
     } timer[kStreamTimers];
@@ -164,6 +165,7 @@ void release_ctx(DeviceCtx &c)
     for (auto &t : c.timer) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
+        if (t.d_ticket) (void)hipFree(t.d_ticket);
         t = DeviceCtx::Timer{};
     }
     c.last_timer = -1;
@@ -224,7 +226,7 @@ int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
 }
 
 using KernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, uint32_t, unsigned long long *,
-                          uint8_t *, const uint8_t *, uint32_t);
+                          uint8_t *, const uint8_t *, uint32_t, uint32_t *);
 
 }  // namespace
 
@@ -232,7 +234,8 @@ using KernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, u
 // -DMCGP_INST_N=<n>) so that the build runs in parallel; here they are only declared.
 namespace mcgp {
 #define X(N_) extern template __global__ void race_kernel_reg<N_>(const KParams *, uint64_t, uint64_t, uint32_t, uint32_t, \
-                                                                  unsigned long long *, uint8_t *, const uint8_t *, uint32_t);
+                                                                  unsigned long long *, uint8_t *, const uint8_t *, uint32_t, \
+                                                                  uint32_t *);
 MCGP_REG_SIZES(X)
 #undef X
 }  // namespace mcgp
@@ -379,6 +382,10 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         if (!c.timer[ti].start) {
             HIP_TRY(hipEventCreate(&c.timer[ti].start));
             HIP_TRY(hipEventCreate(&c.timer[ti].stop));
+            HIP_TRY(hipMalloc(&c.timer[ti].d_ticket, sizeof(uint32_t)));
+        } else if (c.timer[ti].used) {
+            // recycled from another stream: its last launch may still be claiming work from the entry's counter
+            HIP_TRY(hipEventSynchronize(c.timer[ti].stop));
         }
         c.timer[ti].stream = stream;
         c.timer[ti].used = true;
@@ -390,14 +397,15 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     for (uint64_t done = 0; done < n_sims; done += cap) {
         const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
         launch_geometry(c, (uint32_t)kp.n, is_reg, kernel, m, &grid, &block, &lds);
-        // units of work: the register kernel's waves claim chunks of 64 simulations, a block of the generic kernel
-        // takes batches of `block` (both < 2^32 because m < 2^32)
+        // units of work: the register kernel's waves claim chunks of 64 simulations from the stream's counter, a block
+        // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
         const uint64_t unit = is_reg ? 64u : block;
         const uint64_t n_batches = (m + unit - 1) / unit;
+        if (is_reg) HIP_TRY(hipMemsetAsync(c.timer[ti].d_ticket, 0, sizeof(uint32_t), stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
                            (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
                            d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
-                           (uint32_t)n_batches);
+                           (uint32_t)n_batches, c.timer[ti].d_ticket);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c.timer[ti].stop, stream));

@@ -347,13 +347,13 @@ __device__ __forceinline__ double bpermute_f64(double x, int src_lane)   // src_
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(x));
     return __hiloint2double(hi, lo);
 }
-// The wave's next work ticket: one lane takes it from the block's counter in LDS, every lane gets the value
-// (wave-uniform).  `turn` and `waves` are for the host emulation, whose threads run one after another.
-__device__ __forceinline__ uint32_t next_ticket(uint32_t lds_addr, uint32_t /*tid*/, uint32_t /*turn*/, int /*waves*/)
+// The wave's next work ticket: one lane takes it from the launch's counter in device memory, every lane gets the
+// value (wave-uniform).  `turn` and `waves` are for the host emulation, whose threads run one after another.
+__device__ __forceinline__ uint32_t next_ticket(uint32_t *counter, uint32_t /*tid*/, uint32_t /*turn*/, int /*waves*/)
 {
     uint32_t t = 0u;
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
-        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds_addr), "v"(1u) : "memory");
+        t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
 // true if the predicate holds in ANY lane of the wavefront (wave-uniform result)

@@ -101,7 +101,8 @@ __device__ __forceinline__ void update_positions(const Rows &s, int n, bool drs_
 __global__ void __launch_bounds__(512)
 race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
             uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
-            uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches)
+            uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches,
+            uint32_t * /*ticket: the register kernel's work counter; batches are dealt out by block index here*/)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;

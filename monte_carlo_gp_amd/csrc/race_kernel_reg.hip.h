@@ -96,16 +96,18 @@ __host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
            (size_t)n * n * 8;
 }
 // Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this), chosen by measurement
-// (one box, 10^7 simulations): N = 10 39.0 ms at 4 waves, 40.7 at 3, 59.1 at 5; N = 20 100.3 at 3 against 118 at 2;
-// N = 21 112.7 at 2, 116.8 at 3 (the 168-register budget starts to spill); N = 25 139 at 2, 185 at 3.
+// for every field size (tools/sweep_waves.sh, one box, 4x10^6 simulations, profiles/r3_sweep_waves.txt): e.g. N = 10
+// 13.2 ms at 4 waves, 13.6 at 3, 18.1 at 5; N = 20 32.3 at 3, 51.6 at 4 (spills); N = 22 37.0 at 3, 39.9 at 2; N = 23
+// 42.3 at 2, 51.1 at 3 (the LDS rows of 23 cars leave room for 10 waves per CU only).  N = 4 is the one irregular
+// entry: above 4 waves the compiler moves its arrays to scratch (288 B per lane) and it runs 2-4x slower.
 #ifdef MCGP_MIN_WAVES
 __host__ __device__ constexpr int reg_min_waves(int) { return MCGP_MIN_WAVES; }
 #else
-__host__ __device__ constexpr int reg_min_waves(int n) { return n <= 10 ? 4 : n <= 20 ? 3 : 2; }
+__host__ __device__ constexpr int reg_min_waves(int n) { return n <= 6 ? (n == 4 ? 4 : 6) : n <= 11 ? 4 : n <= 22 ? 3 : 2; }
 #endif
-// Waves per block: the (waves per block, blocks per CU) pair that keeps the most waves resident within the
-// LDS budget and the kernel's waves per SIMD; among equals at least 4 waves per block (fewer copies of the
-// shared tables), then the smaller block.
+// Waves per block: the (waves per block, blocks per CU) pair that keeps the most waves resident within the LDS
+// budget and the kernel's waves per SIMD; among equals a multiple of 4 waves per block (a block's waves go round the
+// 4 SIMDs: two blocks of 6 load them 4, 4, 2, 2), then the larger block (fewer copies of the shared tables).
 constexpr size_t kLdsReserve = 256;             // kept free: the block must fit beside what the runtime itself may take
 __host__ __device__ constexpr int reg_block_waves(int n)
 {
@@ -114,7 +116,9 @@ __host__ __device__ constexpr int reg_block_waves(int n)
     for (int w = 1; w <= 16; ++w) {
         int b = (int)((kLdsPerCu - kLdsReserve) / (shared_lds_bytes_reg(n) + (size_t)w * 64 * per_thread_lds_bytes_reg(n)));
         if (b * w > cap) b = cap / w;
-        if (b >= 1 && (b * w > best || (b * w == best && waves < 4))) { best = b * w; waves = w; }
+        if (b < 1) continue;
+        const bool whole = w % 4 == 0, whole_now = waves % 4 == 0;
+        if (b * w > best || (b * w == best && (whole > whole_now || whole == whole_now))) { best = b * w; waves = w; }
     }
     return waves;
 }
@@ -131,7 +135,6 @@ struct RegGeo {
     static constexpr uint32_t oIc = oDrvB + (kMaxCars + N) * 16;  // [compound][driver] {eff f64, pit word u32, DNF threshold u32}
     static constexpr uint32_t oComp = oIc + ((kNumCompounds - 1) * kMaxCars + N) * 16;   // {delta f64, pad} x 8, 16 B each
     static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}              (lap time)
-    static constexpr uint32_t oTicket = oDrs + 8;                 // u32 in the first pad: the block's next unclaimed wave-chunk
     static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, pad}, {drs_delta 2^31, pad}         (overtake pace)
     static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
     static constexpr uint32_t oHist = oLut + 128;                 // u32[N x N]
@@ -434,7 +437,7 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
     if (tid < 2) {
         double *r = reinterpret_cast<double *>(smem + G::oDrs + tid * 16);
         r[0] = tid ? P->drs_delta : 0.0;
-        r[1] = 0.0;                                              // (tid 0: also the chunk ticket G::oTicket = 0)
+        r[1] = 0.0;
         double *q = reinterpret_cast<double *>(smem + G::oDrsB + tid * 16);
         q[0] = tid ? P->drs_delta * 2147483648.0 : 0.0;
         q[1] = 0.0;
@@ -475,14 +478,16 @@ __device__ __forceinline__ void reg_flush_hist(unsigned char *smem, uint32_t tid
     }
 }
 
-// Phase 2: the block's simulations, one full race per lane.  The unit of work is a WAVE-CHUNK of 64 consecutive
-// simulations; block b owns chunks b, b + n_blocks, ... and its waves claim them one at a time from a ticket in LDS,
-// so a wave that runs faster than its neighbours (an odd number of waves per SIMD does not share the VALU issue
-// slots evenly, tools/valu_peak.hip) takes more chunks instead of idling at the end.  Which wave runs a simulation
-// changes nothing in its result: every draw is addressed by the simulation's global id.
+// Phase 2: the simulations, one full race per lane.  The unit of work is a WAVE-CHUNK of 64 consecutive simulations,
+// and every wave of the launch claims its next chunk from one ticket counter in device memory (zeroed by the host
+// before the launch) until the chunks run out: a wave that runs faster than its neighbours takes more of them instead
+// of idling at the end.  That matters at an odd number of waves per SIMD, where the VALU issue slots are not shared
+// evenly (tools/valu_peak.hip: with a fixed share per wave, 3 waves per SIMD ran 14 % slower), and it evens out blocks,
+// CUs and the tail of the launch as well.  Which wave runs a simulation changes nothing in its result: every draw is
+// addressed by the simulation's global id.
 template <int N>
 __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid,
-                                             uint32_t block_index, uint32_t n_blocks, uint64_t n_sims,
+                                             uint32_t *__restrict__ ticket, uint64_t n_sims,
                                              uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
                                              uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid,
                                              uint32_t n_chunks)
@@ -535,9 +540,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     };
 
     for (uint32_t turn = 0u;; ++turn) {
-        const uint64_t chunk = (uint64_t)block_index + (uint64_t)next_ticket(G::oTicket, tid, turn, G::kWaves) * (uint64_t)n_blocks;
-        if (chunk >= (uint64_t)n_chunks) break;
-        const uint64_t local = chunk * 64ull + (uint64_t)(tid & 63u);
+        const uint32_t chunk = next_ticket(ticket, tid, turn, G::kWaves);
+        if (chunk >= n_chunks) break;                            // (every wave ends on its first ticket past the end)
+        const uint64_t local = (uint64_t)chunk * 64ull + (uint64_t)(tid & 63u);
         // A lane past the end of the run still runs a race while any lane of its wave has one to run -- the wave's
         // lanes work for each other in the event handler (lane = car) -- but records nothing.
         const bool live = local < n_sims;
@@ -601,16 +606,18 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     const double cdf_last = acc;
                     // searchsorted(cdf / cdf[-1], u, 'right'): the first driver with cdf[d] / cdf_last > u.  The
                     // quotient is only formed when the answer is not already certain: fl(x / c) <= u for every
-                    // x <= fl(u c) (1 - 2^-50) and fl(x / c) > u for every x >= fl(u c) (1 + 2^-50) (the three
+                    // x <= fl(u c) (1 - 2^-50) and fl(x / c) > u for every x > fl(u c) (1 + 2^-50) (the three
                     // roundings involved move a value by at most 2^-52 relative), so the division -- a dozen
                     // instructions on this hardware -- runs only for a cdf entry within 2^-49 of the threshold.
+                    // The comparisons are strict: u = 0 (one draw in 2^32) makes both bounds 0, and a cdf entry of 0
+                    // -- the drivers placed before the first remaining one -- is not above it.
                     const double uc = u * cdf_last;
                     const double sure_le = uc * (1.0 - 0x1p-50), sure_gt = uc * (1.0 + 0x1p-50);
                     uint32_t above = 0u, unsure = 0u;                                    // bit d: cdf[d] / cdf_last > u / not certain
 #pragma unroll
                     for (int d = 0; d < N; ++d) {
-                        above |= p[d] >= sure_gt ? (1u << d) : 0u;
-                        unsure |= (p[d] > sure_le && !(p[d] >= sure_gt)) ? (1u << d) : 0u;
+                        above |= p[d] > sure_gt ? (1u << d) : 0u;
+                        unsure |= (p[d] > sure_le && !(p[d] > sure_gt)) ? (1u << d) : 0u;
                     }
                     if (unsure != 0u) {
 #pragma unroll
@@ -1159,7 +1166,8 @@ template <int N>
 __global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
-                uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks)
+                uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,
+                uint32_t *__restrict__ ticket)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // host and kernel must agree on the geometry, and the rows are addressed by absolute LDS address
@@ -1167,8 +1175,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) __builtin_trap();
     reg_load_tables<N>(P, smem, threadIdx.x);
     __syncthreads();
-    reg_simulate<N>(P, smem, threadIdx.x, blockIdx.x, gridDim.x, n_sims, sim_offset, seed_lo, seed_hi, orders,
-                    fixed_grid, n_chunks);
+    reg_simulate<N>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks);
     __syncthreads();
     reg_flush_hist<N>(smem, threadIdx.x, hist);
 }

@@ -265,6 +265,43 @@ def test_parameter_block_eviction_waits_for_every_stream(require_gpu):
         assert np.array_equal(d.cpu().numpy().reshape(p.n, p.n), O.Problem(case).run(3000, rng=O.RNG_PHILOX, seed=seed)['hist']), name
 
 
+@pytest.mark.parametrize('sim', [33884187, 666225793])
+def test_grid_draw_of_exactly_zero(require_gpu, sim):
+    """S60, seed 42: the two simulations of the first 10^9 whose grid sampling draws the word 0 (u = 0.0): the first
+    REMAINING driver with mass is chosen, not a placed one whose cdf entry is 0 (tests/test_kernel_host_build.py)."""
+    case = O.load_case('S60')
+    ref = O.Problem(case).run(128, rng=O.RNG_PHILOX, seed=42, sim_offset=sim - 64, want_orders=True)
+    hist, _, orders = product_run(case, 128, 42, sim_offset=sim - 64, orders=True)
+    assert sorted(orders[64].tolist()) == list(range(20))
+    assert np.array_equal(orders, ref['orders'])
+    assert np.array_equal(hist, ref['hist'])
+
+
+def test_more_streams_in_flight_than_work_counters(require_gpu):
+    """Every stream's launches claim their 64-simulation chunks from that stream's work counter (zeroed on the stream
+    before each launch); the library keeps 8 such entries per device and recycles the least recently used one behind
+    its last launch.  Eleven streams, all launched before anything is awaited, three rounds: every result must be
+    the run made alone -- a counter shared by two live launches would drop or repeat chunks (column sums != n)."""
+    import torch
+    dev = torch.device('cuda', 0)
+    streams = [torch.cuda.Stream(dev) for _ in range(11)]
+    case, p, g = _device_problem('S60')
+    n_sims = 300_000
+    alone = {seed: product_run(case, n_sims, seed)[0] for seed in (1, 2, 3)}
+    for seed in (1, 2, 3):
+        bufs = [torch.zeros(p.n * p.n, dtype=torch.int64, device=dev) for _ in streams]
+        torch.cuda.synchronize(dev)
+        for st, d in zip(streams, bufs):
+            _run_on_stream(p, g, n_sims, seed, st, d)
+        torch.cuda.synchronize(dev)
+        for d in bufs:
+            h = d.cpu().numpy().reshape(p.n, p.n)
+            assert (h.sum(axis=0) == n_sims).all()
+            assert np.array_equal(h, alone[seed])
+    slice_ref = O.Problem(case).run(4096, rng=O.RNG_PHILOX, seed=1)['hist']
+    assert np.array_equal(product_run(case, 4096, 1)[0], slice_ref)
+
+
 def test_orders_into_an_unaligned_device_buffer(require_gpu):
     """mcgp_run_device with d_orders one byte off dword alignment: the kernel falls back from packed dword stores
     to byte stores (n = 20 and n = 24 are the sizes that otherwise take the packed path)."""

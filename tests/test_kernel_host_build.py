@@ -43,6 +43,22 @@ def test_fuzzed_configurations():
     assert len(skipped) <= 3, skipped
 
 
+# S60, seed 42: the two simulations of the first 10^9 in which a GRID draw is the word 0, i.e. u = 0.0 exactly (found by
+# tests/test_gpu_scale.py's 10^9 run, whose Latin-square check caught a driver placed twice: a cdf entry of 0 -- a
+# driver already placed -- had been taken for "above u")
+ZERO_GRID_DRAWS = (33884187, 666225793)
+
+
+@pytest.mark.parametrize('sim', ZERO_GRID_DRAWS)
+def test_grid_draw_of_exactly_zero(sim):
+    case = O.load_case('S60')
+    ref = O.Problem(case).run(3, rng=O.RNG_PHILOX, seed=42, sim_offset=sim - 1, want_orders=True)
+    hist, orders = K.run(case, 3, 42, sim_offset=sim - 1)
+    assert sorted(orders[1].tolist()) == list(range(20))
+    assert np.array_equal(orders, ref['orders'])
+    assert np.array_equal(hist, ref['hist'])
+
+
 def test_offsets_and_64bit_seeds():
     case = O.load_case('S50')
     seed, base = 0xDEADBEEFCAFEF00D, (1 << 40) + 12345

@@ -68,7 +68,7 @@ static int run_size(const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offse
         const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
         for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N>(&kp, mcgp::smem, t);
         for (uint32_t t = 0; t < B; ++t)
-            mcgp::reg_simulate<N>(&kp, mcgp::smem, t, 0u, 1u, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32),
+            mcgp::reg_simulate<N>(&kp, mcgp::smem, t, nullptr, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32),
                                   orders, fixed_grid, n_chunks);
         for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N>(mcgp::smem, t, hist);
         return 0;

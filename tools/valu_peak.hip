@@ -46,6 +46,7 @@ DEFINE_KERNEL(k_add_f64, F64_DECL, asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[
 DEFINE_KERNEL(k_mul_f64, F64_DECL, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[j]) : "v"(b)), a[j])
 DEFINE_KERNEL(k_min_f64, F64_DECL, asm volatile("v_min_f64 %0, %0, %1" : "+v"(a[j]) : "v"(b)), a[j])
 DEFINE_KERNEL(k_cmp_f64, F64_DECL, asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(a[j]), "v"(b) : "vcc"), a[j])
+DEFINE_KERNEL(k_cmp_u32, U32_DECL, asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[j]), "v"(b) : "vcc"), (double)a[j])
 DEFINE_KERNEL(k_cvt_f64_u32, F64_DECL; uint32_t q = threadIdx.x, asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a[j]) : "v"(q)), a[j])
 DEFINE_KERNEL(k_cndmask_vop2, U32_DECL, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[j]) : "v"(b) : ), (double)a[j])
 DEFINE_KERNEL(k_cndmask_vop3, U32_DECL; unsigned long long m = 0x5555555555555555ull + blockIdx.x, asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[j]) : "v"(b), "s"(m)), (double)a[j])
@@ -105,7 +106,7 @@ int main()
 {
     const Case cases[] = {
         {"v_fma_f64", k_fma_f64}, {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64}, {"v_min_f64", k_min_f64},
-        {"v_cmp_gt_f64 (vcc)", k_cmp_f64}, {"v_cvt_f64_u32", k_cvt_f64_u32}, {"v_cndmask_b32 (VOP2, vcc)", k_cndmask_vop2},
+        {"v_cmp_gt_f64 (vcc)", k_cmp_f64}, {"v_cmp_lt_u32 (vcc)", k_cmp_u32}, {"v_cvt_f64_u32", k_cvt_f64_u32}, {"v_cndmask_b32 (VOP2, vcc)", k_cndmask_vop2},
         {"v_cndmask_b32_e64 (SGPR mask)", k_cndmask_vop3}, {"v_add_u32", k_add_u32}, {"v_and_b32", k_and_b32},
         {"v_xor_b32", k_xor_b32}, {"v_bfe_u32", k_bfe_u32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_and_or_b32", k_and_or_b32},
         {"v_mad_u64_u32", k_mad_u64_u32}, {"v_fma_f32", k_fma_f32}, {"v_mov_b32", k_mov_b32},
