@@ -18,7 +18,8 @@ The JSON line printed by rank 0 carries, besides the contract fields,
                  kernel time (hipEvents on the launch stream) against 1024 SIMDs x 2.4 GHz / 2 cycles (the guide's
                  SIMD-32 rate; `frac`), and against the 4-cycle rate that the datasheet's 78.6 TFLOP/s of vector FP64
                  implies (`frac_at_fp64_rate`), and against the ceiling of the kernel's own instruction mix with issue
-                 costs measured per class (`frac_of_mix_ceiling`), with the PMC's own VALUBusy beside them; `traffic` = HBM bytes per
+                 costs measured per class (`frac_of_mix_ceiling`); the PMC's VALUBusy formula is quoted beside them but is not a
+                 utilisation on this hardware (it reads 1.07 for this kernel); `traffic` = HBM bytes per
                  launch from the PMC passes; roofline.hbm_nominal = the 20 algorithmic bytes per simulation
                  against the 8 TB/s HBM peak -- evidence that the path is NOT memory bound.  Counters are quoted only
                  when profiles/r3_counters.json carries the source hash of the loaded library (else null, reason in
@@ -46,7 +47,9 @@ ALGORITHMIC_BYTES_PER_SIM = 20          # the n x u8 finishing order, SURVEY.md 
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TINST = 1024 * 2.4e9 / 2 / 1e12   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 # the rate the datasheet's vector FP64 peak implies: 78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz, i.e. one
-# wave64 instruction per 4 cycles -- also what the PMC's VALUBusy (4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles) measures
+# wave64 instruction per 4 cycles.  (The profiler's VALUBusy formula, 4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles, assumes that
+# rate for every instruction; with the 2-cycle class in the mix it overshoots 1 -- 1.07 for the S60 kernel -- and is
+# quoted as `valu_busy_profiled` for reference only.)
 VALU_PEAK_TINST_4CYCLE = 1024 * 2.4e9 / 4 / 1e12
 COUNTERS_FILE = 'r3_counters.json'
 
@@ -336,8 +339,11 @@ def main():
         roof.update({
             'kernel': r['kernel'], 'kernel_ms_avg': kavg_ms, 'counters_note': why_not,
             'peak_note': 'peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: SIMD-32); '
-                         'peak_at_fp64_rate = / 4 cycles, the rate behind the 78.6 TFLOP/s vector FP64 peak and behind '
-                         "the profiler's VALUBusy; the kernel's instructions are binary64 / VOP3 ones for the most part",
+                         'peak_at_fp64_rate = / 4 cycles, the rate behind the 78.6 TFLOP/s vector FP64 peak (the kernel\'s '
+                         'instructions are binary64 / VOP3 ones for the most part); peak_for_instruction_mix weights the '
+                         'two measured issue costs (tools/valu_peak.hip) by the lap loop\'s instruction classes and is the '
+                         'ceiling to read frac_of_mix_ceiling against; valu_busy_profiled is the rocprof VALUBusy formula, '
+                         'which overshoots 1 when 2-cycle instructions are in the mix',
             'hbm_nominal': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': achieved / HBM_PEAK_GBS,
                             'note': 'nominal: 20 algorithmic bytes per simulation (the finishing order) over the kernel '

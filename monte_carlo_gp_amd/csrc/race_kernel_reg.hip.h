@@ -107,18 +107,22 @@ __host__ __device__ constexpr int reg_min_waves(int n) { return n <= 6 ? (n == 4
 #endif
 // Waves per block: the (waves per block, blocks per CU) pair that keeps the most waves resident within the LDS
 // budget and the kernel's waves per SIMD; among equals a multiple of 4 waves per block (a block's waves go round the
-// 4 SIMDs: two blocks of 6 load them 4, 4, 2, 2), then the larger block (fewer copies of the shared tables).
+// 4 SIMDs: two blocks of 6 load them 4, 4, 2, 2), then the block nearest to 8 waves (1024-thread blocks make the
+// register allocator spill more -- N = 10: 164 B per lane against 48 --, many small ones copy the tables more often).
+#ifndef MCGP_MAX_BLOCK_WAVES
+#define MCGP_MAX_BLOCK_WAVES 16
+#endif
 constexpr size_t kLdsReserve = 256;             // kept free: the block must fit beside what the runtime itself may take
+__host__ __device__ constexpr int block_shape_rank(int w) { return (w % 4 == 0 ? 0 : 100) + (w <= 8 ? 2 * (8 - w) : w - 8); }
 __host__ __device__ constexpr int reg_block_waves(int n)
 {
     const int cap = 4 * reg_min_waves(n);
     int best = 0, waves = 1;
-    for (int w = 1; w <= 16; ++w) {
+    for (int w = 1; w <= MCGP_MAX_BLOCK_WAVES; ++w) {
         int b = (int)((kLdsPerCu - kLdsReserve) / (shared_lds_bytes_reg(n) + (size_t)w * 64 * per_thread_lds_bytes_reg(n)));
         if (b * w > cap) b = cap / w;
         if (b < 1) continue;
-        const bool whole = w % 4 == 0, whole_now = waves % 4 == 0;
-        if (b * w > best || (b * w == best && (whole > whole_now || whole == whole_now))) { best = b * w; waves = w; }
+        if (b * w > best || (b * w == best && block_shape_rank(w) < block_shape_rank(waves))) { best = b * w; waves = w; }
     }
     return waves;
 }
