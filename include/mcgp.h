@@ -110,7 +110,11 @@ int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
  * from an earlier call on ANOTHER stream is re-used only behind an event wait on
  * that upload, and is overwritten (4 blocks are cached) only after the launches of
  * EVERY stream that used it have completed.  Runs of 2^32 simulations or more are split into several launches
- * on the stream (the per-block histogram counts in 32 bits). */
+ * on the stream (the per-block histogram counts in 32 bits).  Every launch is preceded, on the same stream, by a
+ * 4-byte memset of the stream's work counter (the kernel's waves claim their simulations from it; the library
+ * keeps a counter per stream, 8 per device, and recycles the least recently used one behind its last launch):
+ * what the call enqueues is {upload if the block changed, memset, kernel} per launch, all capturable.  Results do
+ * not depend on which wave ran which simulation. */
 int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs,
                         uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
                         int32_t device, void *stream, uint64_t *d_hist, uint8_t *d_orders);

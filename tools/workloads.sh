@@ -6,5 +6,5 @@ for wl in ${WORKLOADS:-S60 S78 S50 EVT HET DMP WET N10 N22 N25}; do
 import json, sys
 d = json.load(sys.stdin); r = d['roofline']
 print(json.dumps({'workload': '$wl', 'value': d['value'], 'kernel_ms_avg': r['kernel_ms_avg'], 'kernel': r['kernel'],
-                  'launch': d.get('launch'), 'steps': d['steps']}))"
+                  'launch': d.get('valu', {}).get('launch'), 'steps': d['steps']}))"
 done
