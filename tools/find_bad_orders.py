@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""Scan a range of simulations for finishing orders that are not permutations (diagnostic; GPU box).
-    python tools/find_bad_orders.py [WORKLOAD] [N_TOTAL] [SEED]  -> gpurun_out/bad_orders.txt"""
+"""Scan simulations for finishing orders that are not permutations of the drivers (diagnostic; GPU box): every order
+is written to device memory, 20 M at a time, and checked there; the summed histogram's row and column sums too.
+
+    python tools/find_bad_orders.py SEED N_TOTAL WORKLOAD [WORKLOAD ...]     -> gpurun_out/bad_orders.txt (appended)
+
+WORKLOAD: a golden case, N<k> (bench.py's k-car field), FUZZ (every case of tests/golden/fuzz_cases.json) or ALLN
+(N2 .. N32)."""
 import ctypes as C
+import json
 import os
 import sys
 
@@ -13,39 +19,61 @@ import torch
 from monte_carlo_gp_amd import RaceConfig, _native as N
 from monte_carlo_gp_amd.simulation import RaceSimulator, _Problem, _dptr
 import oracle_py as O
+import bench
 
-name = sys.argv[1] if len(sys.argv) > 1 else 'S60'
-n_total = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
-seed = int(sys.argv[3]) if len(sys.argv) > 3 else 42
-case = O.load_case(name)
-drivers = list(case['grid_probs'])
-p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
-             case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
-g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+seed = int(sys.argv[1])
+n_total = int(float(sys.argv[2]))
+names = []
+with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
+    fuzz = json.load(f)
+for a in sys.argv[3:]:
+    if a == 'FUZZ':
+        names += ['FUZZ:' + k for k in fuzz]
+    elif a == 'ALLN':
+        names += [f'N{k}' for k in range(2, 33)]
+    else:
+        names.append(a)
 dev = torch.device('cuda', 0)
 stream = torch.cuda.current_stream(dev)
-n = p.n
-step = 20_000_000
-full = (1 << n) - 1
-out = open(os.path.join(ROOT, 'gpurun_out', 'bad_orders.txt'), 'w')
-orders = torch.zeros(step * n, dtype=torch.uint8, device=dev)
-hist = torch.zeros(n * n, dtype=torch.int64, device=dev)
-bad_total = 0
-for off in range(0, n_total, step):
-    cnt = min(step, n_total - off)
-    N.check(N.lib().mcgp_run_device(C.byref(p.cfg), C.byref(p.drv), _dptr(g), n, cnt, off, seed, 0,
-                                    C.c_void_p(stream.cuda_stream), C.c_void_p(hist.data_ptr()), C.c_void_p(orders.data_ptr())))
-    torch.cuda.synchronize(dev)
-    o = orders[:cnt * n].view(cnt, n).to(torch.int64)
-    mask = (torch.ones_like(o) << o).sum(dim=1)
-    bad = torch.nonzero(mask != full).flatten()
-    for b in bad.tolist():
-        line = f'sim {off + b} order {o[b].tolist()}'
-        print(line, flush=True)
-        out.write(line + '\n')
-        out.flush()
-    bad_total += len(bad)
-    print(f'scanned {off + cnt} bad so far {bad_total}', flush=True)
-h = hist.cpu().numpy().reshape(n, n)
-print('row sums off:', (h.sum(axis=1) - n_total).tolist())
-out.write(f'total bad {bad_total}\n')
+out = open(os.path.join(ROOT, 'gpurun_out', 'bad_orders.txt'), 'a')
+grand = 0
+for name in names:
+    if name.startswith('FUZZ:'):
+        case = fuzz[name[5:]]
+    elif name[:1] == 'N' and name[1:].isdigit() and name != 'N10':
+        case = bench.load_workload(name)[0]
+    else:
+        case = O.load_case(name)
+    drivers = list(case['grid_probs'])
+    p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
+                 case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
+    g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
+    n = p.n
+    step = min(20_000_000, n_total)
+    full = (1 << n) - 1
+    orders = torch.zeros(step * n, dtype=torch.uint8, device=dev)
+    hist = torch.zeros(n * n, dtype=torch.int64, device=dev)
+    bad_total = 0
+    for off in range(0, n_total, step):
+        cnt = min(step, n_total - off)
+        N.check(N.lib().mcgp_run_device(C.byref(p.cfg), C.byref(p.drv), _dptr(g), n, cnt, off, seed, 0,
+                                        C.c_void_p(stream.cuda_stream), C.c_void_p(hist.data_ptr()), C.c_void_p(orders.data_ptr())))
+        torch.cuda.synchronize(dev)
+        o = orders[:cnt * n].view(cnt, n).to(torch.int64)
+        mask = (torch.ones_like(o) << o).sum(dim=1)
+        bad = torch.nonzero(mask != full).flatten()
+        for b in bad.tolist()[:20]:
+            out.write(f'{name} sim {off + b} order {o[b].tolist()}\n')
+        bad_total += len(bad)
+        del o, mask, bad
+    h = hist.cpu().numpy().reshape(n, n)
+    off_by = int(max(np.abs(h.sum(axis=1) - n_total).max(), np.abs(h.sum(axis=0) - n_total).max()))
+    line = (f'{name} n={n} laps={case["config"]["total_laps"]} kernel={N.lib().mcgp_last_kernel_name(0).decode()} sims={n_total} seed={seed}: '
+            f'non-permutations {bad_total}, row / column sums off by at most {off_by}')
+    print(line, flush=True)
+    out.write(line + '\n')
+    out.flush()
+    grand += bad_total + off_by
+    del orders, hist
+print('TOTAL anomalies', grand)
+out.write(f'TOTAL anomalies {grand}\n')
