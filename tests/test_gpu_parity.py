@@ -265,10 +265,14 @@ def test_parameter_block_eviction_waits_for_every_stream(require_gpu):
         assert np.array_equal(d.cpu().numpy().reshape(p.n, p.n), O.Problem(case).run(3000, rng=O.RNG_PHILOX, seed=seed)['hist']), name
 
 
+@pytest.mark.parametrize('generic', [False, True])
 @pytest.mark.parametrize('sim', [33884187, 666225793])
-def test_grid_draw_of_exactly_zero(require_gpu, sim):
+def test_grid_draw_of_exactly_zero(require_gpu, monkeypatch, sim, generic):
     """S60, seed 42: the two simulations of the first 10^9 whose grid sampling draws the word 0 (u = 0.0): the first
-    REMAINING driver with mass is chosen, not a placed one whose cdf entry is 0 (tests/test_kernel_host_build.py)."""
+    REMAINING driver with mass is chosen, not a placed one whose cdf entry is 0 (tests/test_kernel_host_build.py).
+    Both kernels."""
+    if generic:
+        monkeypatch.setenv('MCGP_FORCE_GENERIC', '1')
     case = O.load_case('S60')
     ref = O.Problem(case).run(128, rng=O.RNG_PHILOX, seed=42, sim_offset=sim - 64, want_orders=True)
     hist, _, orders = product_run(case, 128, 42, sim_offset=sim - 64, orders=True)
