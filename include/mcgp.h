@@ -148,6 +148,24 @@ int32_t mcgp_run_from_ratings(const mcgp_config *cfg, const mcgp_drivers *drv, c
                               uint64_t sim_offset, uint64_t seed, int32_t device, uint64_t *hist_out,
                               double *grid_probs_out);
 
+/* Elo updates of a whole season on the device ("next" row f4): the events of F1EloSystem.update_quali_ratings
+ * (reference src/elo.py:45-83) and update_race_ratings (:85-122), applied in order in ONE kernel launch with the
+ * ratings resident in LDS between events.  Per event e: kind[e] = 0 updates the qualifying ratings, 1 the race
+ * ratings; k[e] = the K factor set_recency_weight (:13-38) leaves for it; count[e] = m entries of the result list,
+ * who[e * n_drivers + j] = driver index of entry j, value[e * n_drivers + j] = its best lap time (qualifying) or
+ * finishing position (race): lower wins, equal values tie.  Every entry's delta is the sum over the other entries,
+ * in list order, of k (actual - expected) / (m - 1) with the ratings BEFORE the event; all deltas are applied
+ * afterwards; m < 2 changes nothing (:54-56, :93-94).  ratings = [2][n_drivers] (qualifying row, race row), in and
+ * out, with drivers not seen yet at the caller's initial rating (the reference creates them at that value on first
+ * appearance, :59-61).  after_out (optional, NULL to skip) = [n_events][2][n_drivers], the ratings after each
+ * event.  `10 ** exponent` is the library's own (csrc/elo_update.h): bit-identical to the CPU oracle's restatement
+ * of the same text and within a few ulp of the reference's ratings.  MCGP_E_BAD_ARG: n_drivers out of [1, 32], an
+ * entry count above n_drivers, a driver index >= n_drivers or listed twice in one event, a kind other than 0 / 1,
+ * a non-finite k, value or rating. */
+int32_t mcgp_elo_season(uint32_t n_drivers, uint32_t n_events, const int32_t *kind, const double *k,
+                        const uint32_t *count, const uint8_t *who, const double *value, double *ratings,
+                        double *after_out, int32_t device);
+
 /* Measurement hooks (bench.py): duration in ms of the race kernel(s) of a call, from
  * hipEvents the library records on the call's launch stream around its launches
  * (the query synchronises on the stop event).  Every stream keeps its own pair of

@@ -144,7 +144,7 @@ _lib = None
 
 EXPORTS = ('mcgp_abi_version', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
            'mcgp_simulate_race', 'mcgp_grid_probs', 'mcgp_run_from_ratings', 'mcgp_last_kernel_ms',
-           'mcgp_stream_kernel_ms',
+           'mcgp_stream_kernel_ms', 'mcgp_elo_season',
            'mcgp_last_launch_info', 'mcgp_last_kernel_name')
 
 
@@ -183,6 +183,10 @@ def lib():
             L.mcgp_run_from_ratings.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), dp, dp, dp, dp, ip,
                                                 C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
                                                 C.POINTER(C.c_uint64), dp]
+        if 'mcgp_elo_season' not in missing:
+            L.mcgp_elo_season.restype = C.c_int32
+            L.mcgp_elo_season.argtypes = [C.c_uint32, C.c_uint32, ip, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), dp,
+                                          dp, dp, C.c_int32]
         L.mcgp_last_kernel_ms.restype = C.c_int32
         L.mcgp_last_kernel_ms.argtypes = [C.c_int32, C.POINTER(C.c_float)]
         if 'mcgp_stream_kernel_ms' not in missing:

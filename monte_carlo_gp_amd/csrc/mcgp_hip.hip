@@ -12,6 +12,7 @@
 
 #define MCGP_FE_FN __host__ __device__ static inline
 #include "frontend_exp.h"
+#include "elo_update.h"
 
 #include <hip/hip_runtime.h>
 
@@ -22,6 +23,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -71,6 +73,45 @@ grid_probs_kernel(const double *__restrict__ in, const int32_t *__restrict__ pen
     }
 }
 
+// A season of Elo updates (reference src/elo.py:45-122) in one block of 32 x 32 threads with the ratings in LDS.
+// Per event: thread (a, b) computes the term of entry a against entry b (csrc/elo_update.h; the one expensive part,
+// a 10^x and a division, all m (m - 1) of them at once); a barrier; thread (a, 0) adds entry a's terms up in list
+// order -- the reference's inner loop, so the sum has its bits --; a barrier; the deltas are applied.
+__global__ void __launch_bounds__(mcgp::kMaxCars * mcgp::kMaxCars)
+elo_season_kernel(int n, int n_events, const int32_t *__restrict__ kind, const double *__restrict__ k,
+                  const uint32_t *__restrict__ count, const uint8_t *__restrict__ who, const double *__restrict__ value,
+                  double *__restrict__ ratings, double *__restrict__ after)
+{
+    constexpr int M = mcgp::kMaxCars;
+    __shared__ double r[2 * M];                           // [kind][driver], row stride n
+    __shared__ double term[M][M + 1];
+    __shared__ double v[M];
+    __shared__ uint8_t w[M];
+    const int t = threadIdx.x, a = t / M, b = t % M;
+    if (t < 2 * n) r[t] = ratings[t];
+    __syncthreads();
+    for (int e = 0; e < n_events; ++e) {
+        const int m = (int)count[e];
+        double *row = r + (kind[e] ? n : 0);
+        if (t < m) {
+            w[t] = who[(size_t)e * n + t];
+            v[t] = value[(size_t)e * n + t];
+        }
+        __syncthreads();
+        if (m >= 2 && a < m && b < m && a != b) term[a][b] = mcgp_elo_term(row[w[a]], v[a], row[w[b]], v[b], k[e], m);
+        __syncthreads();
+        if (m >= 2 && b == 0 && a < m) {
+            double delta = 0.0;
+            for (int j = 0; j < m; ++j)
+                if (j != a) delta = delta + term[a][j];
+            row[w[a]] = row[w[a]] + delta;                // (the terms were all computed from the ratings before the event)
+        }
+        __syncthreads();
+        if (after && t < 2 * n) after[(size_t)e * 2 * n + t] = r[t];
+    }
+    if (t < 2 * n) ratings[t] = r[t];
+}
+
 constexpr int kParamSlots = 4;
 constexpr int kSlotReaders = 8;        // streams with a launch in flight on one parameter block
 constexpr int kStreamTimers = 8;       // streams whose most recent call keeps its own timing events
@@ -118,6 +159,8 @@ struct DeviceCtx {
     } timer[kStreamTimers];
     uint64_t timer_seq = 0;
     int last_timer = -1;
+    unsigned char *d_elo = nullptr;         // scratch of mcgp_elo_season (grow-only)
+    size_t elo_bytes = 0;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     char last_kernel[48] = "";
 };
@@ -162,6 +205,9 @@ void release_ctx(DeviceCtx &c)
     c.d_fe_in = c.d_fe_out = nullptr;
     c.d_fe_pen = nullptr;
     if (c.d_orders) (void)hipFree(c.d_orders);
+    if (c.d_elo) (void)hipFree(c.d_elo);
+    c.d_elo = nullptr;
+    c.elo_bytes = 0;
     for (auto &t : c.timer) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
@@ -602,6 +648,83 @@ int32_t mcgp_grid_probs(const double *quali_rating, const double *teammate_delta
                            c->d_fe_out);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(grid_probs_out, c->d_fe_out, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        return MCGP_OK;
+    };
+    return body();
+}
+
+int32_t mcgp_elo_season(uint32_t n_drivers, uint32_t n_events, const int32_t *kind, const double *k,
+                        const uint32_t *count, const uint8_t *who, const double *value, double *ratings,
+                        double *after_out, int32_t device)
+{
+    const uint32_t n = n_drivers;
+    if (n < 1 || n > MCGP_MAX_CARS) return fail(MCGP_E_BAD_ARG, "n_drivers must be in [1, 32]");
+    if (!ratings) return fail(MCGP_E_BAD_ARG, "ratings is NULL");
+    if (n_events > 0 && (!kind || !k || !count || !who || !value)) return fail(MCGP_E_BAD_ARG, "an event array is NULL");
+    for (uint32_t i = 0; i < 2 * n; ++i)
+        if (!std::isfinite(ratings[i])) return fail(MCGP_E_BAD_ARG, "non-finite rating");
+    for (uint32_t e = 0; e < n_events; ++e) {
+        if (kind[e] != 0 && kind[e] != 1) return fail(MCGP_E_BAD_ARG, "event kind must be 0 (qualifying) or 1 (race)");
+        if (!std::isfinite(k[e])) return fail(MCGP_E_BAD_ARG, "non-finite K factor");
+        if (count[e] > n) return fail(MCGP_E_BAD_ARG, "more entries than drivers in an event");
+        uint32_t seen = 0;
+        for (uint32_t j = 0; j < count[e]; ++j) {
+            const uint32_t d = who[(size_t)e * n + j];
+            if (d >= n) return fail(MCGP_E_BAD_ARG, "driver index out of range in an event");
+            if (seen & (1u << d)) return fail(MCGP_E_BAD_ARG, "a driver is listed twice in one event");
+            seen |= 1u << d;
+            if (!std::isfinite(value[(size_t)e * n + j])) return fail(MCGP_E_BAD_ARG, "non-finite lap time / position");
+        }
+    }
+    DeviceCtx *c = nullptr;
+    int rc = find_ctx(device, &c);
+    if (rc != MCGP_OK) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    // one buffer for everything the kernel reads and writes, packed on the host: one upload, one launch, one
+    // download (the call is latency-bound: a season is a few hundred events for one wavefront)
+    const size_t ne = n_events, row = n;
+    const size_t o_rat = 0, o_after = o_rat + 2 * row * 8, o_k = o_after + (after_out ? ne * 2 * row * 8 : 0);
+    const size_t o_val = o_k + ne * 8, o_kind = o_val + ne * row * 8, o_cnt = o_kind + ne * 4, o_who = o_cnt + ne * 4;
+    const size_t bytes = o_who + ne * row;
+    std::vector<unsigned char> host(bytes - o_k + 2 * row * 8);        // [ratings | inputs]: the after block is output only
+    const size_t in0 = 2 * row * 8;                                    // inputs start here in `host`, at o_k on the device
+    std::memcpy(host.data(), ratings, 2 * row * 8);
+    if (ne) {
+        std::memcpy(host.data() + in0 + (o_k - o_k), k, ne * 8);
+        std::memcpy(host.data() + in0 + (o_val - o_k), value, ne * row * 8);
+        std::memcpy(host.data() + in0 + (o_kind - o_k), kind, ne * 4);
+        std::memcpy(host.data() + in0 + (o_cnt - o_k), count, ne * 4);
+        std::memcpy(host.data() + in0 + (o_who - o_k), who, ne * row);
+    }
+    auto body = [&]() -> int {
+        int r = ensure_ctx_locked(device, *c);
+        if (r != MCGP_OK) return r;
+        HIP_TRY(hipSetDevice(device));
+        if (c->elo_bytes < bytes) {                                    // grow-only scratch of the context
+            if (c->d_elo) (void)hipFree(c->d_elo);
+            c->d_elo = nullptr;
+            c->elo_bytes = 0;
+            HIP_TRY(hipMalloc(&c->d_elo, bytes));
+            c->elo_bytes = bytes;
+        }
+        unsigned char *d = c->d_elo;
+        HIP_TRY(hipMemcpy(d + o_rat, host.data(), 2 * row * 8, hipMemcpyHostToDevice));
+        if (ne) HIP_TRY(hipMemcpy(d + o_k, host.data() + in0, bytes - o_k, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(elo_season_kernel, dim3(1), dim3(mcgp::kMaxCars * mcgp::kMaxCars), 0, nullptr, (int)n, (int)n_events,
+                           reinterpret_cast<const int32_t *>(d + o_kind), reinterpret_cast<const double *>(d + o_k),
+                           reinterpret_cast<const uint32_t *>(d + o_cnt), d + o_who,
+                           reinterpret_cast<const double *>(d + o_val), reinterpret_cast<double *>(d + o_rat),
+                           after_out ? reinterpret_cast<double *>(d + o_after) : nullptr);
+        HIP_TRY(hipGetLastError());
+        if (after_out && ne) {
+            // ratings and the snapshots are adjacent: one download
+            std::vector<double> back(2 * row + ne * 2 * row);
+            HIP_TRY(hipMemcpy(back.data(), d + o_rat, back.size() * 8, hipMemcpyDeviceToHost));
+            std::memcpy(ratings, back.data(), 2 * row * 8);
+            std::memcpy(after_out, back.data() + 2 * row, ne * 2 * row * 8);
+        } else {
+            HIP_TRY(hipMemcpy(ratings, d + o_rat, 2 * row * 8, hipMemcpyDeviceToHost));
+        }
         return MCGP_OK;
     };
     return body();

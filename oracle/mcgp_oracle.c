@@ -850,3 +850,32 @@ int orc_grid_probs(const double *rating, const double *teammate_delta, const dou
         mcgp_fe_grid_row(p[d], form_score[d], circuit_affinity[d], penalty[d], n, out + (size_t)d * n, tmp);
     return 0;
 }
+
+/* ---- a season of Elo updates (reference src/elo.py:40-122) ----
+ * CPU side of the checker for mcgp_elo_season: the same header text as the HIP kernel compiles (elo_update.h), the
+ * events applied one after the other, every delta of an event computed before any is applied. */
+#include "elo_update.h"
+
+double orc_elo_pow10(double x) { return mcgp_elo_pow10(x); }
+
+int orc_elo_season(int32_t n, int32_t n_events, const int32_t *kind, const double *k, const uint32_t *count,
+                   const uint8_t *who, const double *value, double *ratings, double *after_out)
+{
+    if (n < 1 || n > MCGP_ORACLE_MAX_CARS || n_events < 0 || !ratings) return -1;
+    if (n_events > 0 && (!kind || !k || !count || !who || !value)) return -1;
+    for (int e = 0; e < n_events; e++) {
+        const int m = (int)count[e];
+        if (m > n || (kind[e] != 0 && kind[e] != 1)) return -1;
+        double *row = ratings + (kind[e] ? n : 0);
+        const uint8_t *w = who + (size_t)e * n;
+        const double *v = value + (size_t)e * n;
+        if (m >= 2) {                                              /* elo.py:54-56, :93-94 */
+            double delta[MCGP_ORACLE_MAX_CARS];
+            for (int a = 0; a < m; a++) delta[a] = mcgp_elo_delta(row, w, v, m, a, k[e]);
+            for (int a = 0; a < m; a++) row[w[a]] = row[w[a]] + delta[a];             /* :80-83, :119-122 */
+        }
+        if (after_out)
+            for (int i = 0; i < 2 * n; i++) after_out[(size_t)e * 2 * n + i] = ratings[i];
+    }
+    return 0;
+}

@@ -123,6 +123,12 @@ double orc_fe_exp(double x);
 int orc_grid_probs(const double *rating, const double *teammate_delta, const double *form_score,
                    const double *circuit_affinity, const int32_t *penalty, int32_t n, double *out);
 
+/* A season of Elo updates, reference src/elo.py:40-122, with the library's own 10^x (elo_update.h).  Arguments as
+ * mcgp_elo_season (include/mcgp.h); -1 on a malformed argument. */
+double orc_elo_pow10(double x);
+int orc_elo_season(int32_t n, int32_t n_events, const int32_t *kind, const double *k, const uint32_t *count,
+                   const uint8_t *who, const double *value, double *ratings, double *after_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -608,8 +608,57 @@ def _ref_stat_one(case, seed, n_each):
     return h
 
 
+def elo_season():
+    """Three seasons of Elo updates through the reference's F1EloSystem (src/elo.py:13-122): two past seasons at
+    K x 0.7 and K x 1.0, the current one with the race-within-season K; a rookie who appears mid-season, absentees,
+    races with fewer classified finishers than qualifiers, exact lap-time ties, a shared finishing position, a
+    one-entry event (no update).  Ratings of every driver after every event -> elo_season.json."""
+    drivers = list(DRIVER_TEAMS.keys())
+    rookie = 'ROO'
+    rs = np.random.RandomState(2024)
+    skill = {d: 0.04 * i for i, d in enumerate(drivers + [rookie])}
+    e = F1EloSystem()
+    events, after = [], []
+
+    def snapshot():
+        after.append({d: dict(r) for d, r in e.ratings.items()})
+
+    def weekend(field):
+        times = {d: 80.0 + skill[d] + float(rs.normal(0, 0.25)) for d in field}
+        quali = sorted(times.items(), key=lambda kv: kv[1])
+        if rs.rand() < 0.3 and len(quali) > 3:                     # an exact tie on lap time
+            quali[2] = (quali[2][0], quali[1][1])
+        order = sorted(field, key=lambda d: skill[d] + float(rs.normal(0, 0.5)))
+        classified = order[:len(order) - int(rs.randint(0, 4))]
+        race = [(d, i + 1) for i, d in enumerate(classified)]
+        if rs.rand() < 0.15 and len(race) > 5:                     # two cars classified in the same position
+            race[4] = (race[4][0], race[3][1])
+        rs.shuffle(race)                                            # list order is not finishing order
+        return quali, race
+
+    plan = [(2, 6, 6), (1, 6, 6), (0, 24, 24)]                     # (years_ago, races run, total_races)
+    for years_ago, n_races, total in plan:
+        for idx in range(n_races):
+            field = [d for d in drivers if rs.rand() > 0.04]
+            if years_ago == 0 and idx >= 8:
+                field.append(rookie)
+            if years_ago == 0 and idx == 13:
+                field = field[:1]                                   # a one-entry event: n < 2, no update
+            quali, race = weekend(field)
+            for kind, results, fn in (('quali', quali, e.update_quali_ratings), ('race', race, e.update_race_ratings)):
+                e.set_recency_weight(years_ago, idx, total)
+                fn(results)
+                events.append(dict(kind=kind, years_ago=years_ago, race_index=idx, total_races=total, k=e.k,
+                                   results=[[d, v] for d, v in results]))
+                snapshot()
+    out = dict(drivers=drivers + [rookie], initial=e.initial, base_k=e.base_k, events=events, after=after)
+    with open(os.path.join(HERE, 'elo_season.json'), 'w') as f:
+        json.dump(json.loads(json.dumps(out, default=float)), f, indent=0)
+    print(f'elo_season: {len(events)} events', flush=True)
+
+
 def main():
-    what = sys.argv[1:] or ['cases', 'streams', 'grids', 'misc', 'weekend', 'fuzz']
+    what = sys.argv[1:] or ['cases', 'streams', 'grids', 'misc', 'weekend', 'fuzz', 'elo']
     cases = build_cases()
     if 'cases' in what:
         meta = dict(
@@ -634,6 +683,8 @@ def main():
         weekend()
     if 'fuzz' in what:
         fuzz()
+    if 'elo' in what:
+        elo_season()
     if 'stat' in what:
         by = {c['name']: c for c in cases}
         ref_stat(by['S60'], list(range(101, 109)), 25000)

@@ -49,7 +49,7 @@ class OrcTrace(C.Structure):
 
 def build(force=False):
     """Compile the oracle if the shared object is missing or stale."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ('mcgp_oracle.c', 'mcgp_oracle.h', 'normal_table.h', 'frontend_exp.h', 'Makefile')]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ('mcgp_oracle.c', 'mcgp_oracle.h', 'normal_table.h', 'frontend_exp.h', 'elo_update.h', 'Makefile')]
     if (force or not os.path.exists(LIB_PATH)
             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.check_call(['make', '-C', ORACLE_DIR, '-s', '-B'], stdout=subprocess.DEVNULL,
