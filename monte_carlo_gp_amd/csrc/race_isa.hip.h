@@ -252,6 +252,31 @@ __device__ __forceinline__ void bubble_bwd4(double &c0, uint32_t &p0, double &c1
     c0 = l4; p0 = q4;
 }
 
+// ---- selects through VCC ----
+// A select whose mask sits in an SGPR pair is VOP3-encoded (v_cndmask_b32_e64) and occupies the SIMD for ~4.2 cycles; the
+// VOP2 form, which reads its mask from VCC, for ~2.3 (tools/valu_peak.hip).  Where one compare feeds several selects the
+// block is written out: the compare into VCC, the selects right behind.  gfx950 needs two wait states between a VALU write
+// of VCC and a VALU read of it and does not interlock them: at least two independent instructions sit in between.
+
+// One adjacent pair of an overtake pass (reference :516-524, pace deltas x 2^31): the pair is a candidate iff dl > od
+// (NaN -- a retired car -- is not); thr = the draw-word threshold min(ceil(dl), 2^31) of a candidate, 0 otherwise; `next` =
+// `row` advanced by `stride` for a candidate, so that the W-plane address of a pair's draw word is a running sum over the
+// pairs before it instead of a popcount.
+__device__ __forceinline__ void ovt_threshold(double dl, double od, uint32_t row, uint32_t stride, uint32_t &thr, uint32_t &next)
+{
+    double t;
+    asm("v_cmp_lt_f64 vcc, %[od], %[dl]\n\t"
+        "v_ceil_f64 %[t], %[dl]\n\t"
+        "v_cvt_u32_f64 %[thr], %[t]\n\t"
+        "v_min_u32 %[thr], 0x80000000, %[thr]\n\t"
+        "v_cndmask_b32 %[thr], 0, %[thr], vcc\n\t"
+        "v_cndmask_b32 %[next], 0, %[stride], vcc\n\t"
+        "v_add_u32 %[next], %[row], %[next]"
+        : [t] "=&v"(t), [thr] "=&v"(thr), [next] "=&v"(next)
+        : [dl] "v"(dl), [od] "s"(od), [row] "v"(row), [stride] "v"(stride)
+        : "vcc");
+}
+
 // LDS access by ABSOLUTE byte address.  The register kernel declares no static __shared__ data, so its
 // dynamic LDS block starts at address 0 (checked once at kernel entry); addressing it by number instead of
 // through the `extern __shared__` symbol lets the compiler fold every table / row base into the 16-bit
@@ -362,6 +387,8 @@ __device__ __forceinline__ uint32_t next_ticket(uint32_t *counter, uint32_t /*ti
 // select and turn the select into a branch (no instruction is emitted).
 __device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+// the same for a wave-uniform value (an SGPR)
+__device__ __forceinline__ void pin_scalar(uint32_t &x) { asm volatile("" : "+s"(x)); }
 // a wave-uniform pointer the optimiser cannot see through: loads through it stay where they are written
 template <typename T>
 __device__ __forceinline__ void pin_ptr(const T *&p) { asm volatile("" : "+s"(p)); }

@@ -51,6 +51,10 @@
 #endif
 // Race-interrupting events handled by the wave with lane = car (1) or by every lane for itself (0: the same
 // results; kept for A/B runs and for the host debugging build, whose threads run one at a time).
+// Diagnostic (host build, tests): 1 = _sample_grid takes its exact, dividing path for every draw.
+#ifndef MCGP_GRID_EXACT
+#define MCGP_GRID_EXACT 0
+#endif
 #ifndef MCGP_COOPERATIVE_EVENTS
 #define MCGP_COOPERATIVE_EVENTS 1
 #endif
@@ -72,6 +76,7 @@ constexpr uint32_t k3Dnf = 1u << 15;           // directly above the driver inde
 constexpr int k3AgeShift = 16;                 // [16..26] tyre age; lap of retirement once dnf is set
 constexpr uint32_t k3AgeMask = 0x7FFu << k3AgeShift;
 constexpr int k3GposShift = 27;                // [27..31] grid slot (most significant: tie-break)
+constexpr double kAgeFieldUnit = 1.0 / 65536.0;   // tables that multiply (pk & k3AgeMask) carry this factor
 
 // ---- launch geometry and LDS map, fixed per field size ----
 constexpr size_t kLdsPerCu = 160 * 1024;       // gfx950
@@ -354,7 +359,10 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
 {
     bool first = true;
     double leader = 0.0, prev = 0.0;
-    // one straight pass, merged by selects (a few lanes hold retired cars; the wave would pay for the branches)
+    // one straight pass, merged by selects (a few lanes hold retired cars; the wave would pay for the branches).
+    // A RETIRED car's two flags are written like everybody's, with whatever the arithmetic gives: nothing reads them
+    // again (the lap step and the event handler test the dnf bit first, a retired car's overtake pace is NaN whatever
+    // its DRS bit adds, the classification does not look at flags), and not protecting them saves a select per slot.
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const uint32_t p = pk[i];
@@ -364,8 +372,7 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
         const double tbl = t - leader;                                               // :551
         const bool dirty = tbl > 0 && tbl < dirty_thr;
         const bool drs = !first && drs_allowed && (t - prev) < 1.0;                  // :553-558
-        const uint32_t q = (p & ~(k3Drs | k3Dirty)) | (dirty ? k3Dirty : 0u) | (drs ? k3Drs : 0u);
-        pk[i] = act ? q : p;
+        pk[i] = (p & ~(k3Drs | k3Dirty)) | (dirty ? k3Dirty : 0u) | (drs ? k3Drs : 0u);
         prev = act ? t : prev;
         first = first && !act;
     }
@@ -405,13 +412,53 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #define MCGP_PACE_BATCH 10         // slots whose pace gathers are in flight together in an overtake pass
 #endif
 
+// A lower bound of every lap time of the problem, lap 1 included (reference :317-332, :301-306), from the inputs alone:
+// slowest possible fuel effect, DRS gain, the largest negative noise the deviate table can give (|z| < 6.5), the most
+// negative compound delta and degradation x age, the dirty-air penalty if it is negative, the largest start gain.
+// The register kernel relies on times that stay clear of zero: with every lap adding at least kRegTimeFloor seconds
+// and an overtake pass taking at most 0.1 s per pair off a car's time (19 pairs x 3 passes < 6 s per lap), a running
+// car's cumulative time never comes near 0.2 s, so the reference's  max(0.1, ahead - 0.1)  (:528) is  ahead - 0.1.
+// A problem that cannot promise this -- lap times of a few seconds, NaN or infinite inputs -- runs on the generic kernel.
+constexpr double kRegTimeFloor = 8.0;
+__host__ __device__ inline double reg_time_floor(const KParams &kp)
+{
+    const double z_max = 6.5;
+    double floor_ = __builtin_inf();
+    double cdelta_min = __builtin_inf();
+    for (int c = 0; c < 5; ++c) cdelta_min = kp.comp_delta[c] < cdelta_min ? kp.comp_delta[c] : cdelta_min;
+    for (int d = 0; d < kp.n; ++d) {
+        double eff_min = 0.0;
+        for (int c = 0; c < 5; ++c) {
+            const double e = kp.comp_deg[c] * kp.factor[d];
+            eff_min = e < eff_min ? e : eff_min;
+        }
+        const double var = kp.variance[d] < 0 ? -kp.variance[d] : kp.variance[d];
+        const double f = kp.base_pace[d] - var * z_max + eff_min * 2047.0;
+        floor_ = f < floor_ ? f : floor_;
+        if (!(f == f)) return f;                                   // NaN
+    }
+    floor_ = floor_ + cdelta_min - 110.0 * 0.03 - (kp.drs_delta > 0 ? kp.drs_delta : 0.0) +
+             (kp.dirty_pen < 0 ? kp.dirty_pen : 0.0) - 0.5 * 1.5 * z_max;
+    return floor_;
+}
+
 // The register kernel keeps the per-lap DNF threshold in 32 bits: a driver who retires with CERTAINTY on every lap
 // (probability >= 1, threshold 2^32) does not fit and sends the whole problem to the generic kernel.
 __host__ __device__ inline bool reg_kernel_serves(const KParams &kp)
 {
     for (int d = 0; d < kp.n; ++d)
         if (kp.t_dnf[d] > 0xFFFFFFFFull) return false;
-    return true;
+    // The kernel's tables carry powers of two (pace x 2^31, degradation x 2^-16 or x 2^15): exact, a power of two
+    // commutes with every rounding, unless the scaled value leaves the normal range.  Magnitudes no race has, but the
+    // kernel is bit-exact on what it accepts: anything near the ends of binary64 goes to the generic kernel.
+    const double big = 0x1p900, tiny = 0x1p-900;
+    auto scalable = [&](double x) { return x == 0.0 || (x > -big && x < big && (x >= tiny || x <= -tiny)); };
+    for (int d = 0; d < kp.n; ++d) {
+        if (!scalable(kp.base_pace[d]) || !scalable(kp.tire_deg[d])) return false;
+        for (int c = 0; c < 5; ++c)
+            if (!scalable(kp.comp_deg[c] * kp.factor[d])) return false;
+    }
+    return reg_time_floor(kp) >= kRegTimeFloor;
 }
 
 // Phase 1 of a block: fill the block-shared LDS tables (all threads, strided).
@@ -434,7 +481,7 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         // overtake pace, scaled by 2^31 (exact: a power of two commutes with every rounding of base + age x deg):
         // the pace delta then comes out as delta x 2^31, whose ceiling IS the integer threshold of the draw word
         b[0] = P->base_pace[d] * 2147483648.0;
-        b[1] = P->tire_deg[d] * 2147483648.0;
+        b[1] = P->tire_deg[d] * 32768.0;                         // x 2^31 / 2^16: multiplies the age FIELD of pk (age << 16)
         b[2 * kMaxCars] = qnan;                                  // the retired copy: pace = NaN
         b[2 * kMaxCars + 1] = qnan;
     }
@@ -449,8 +496,9 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
     for (uint32_t i = tid; i < (uint32_t)kNumCompounds * N; i += B) {
         const uint32_t c = i / N, d = i % N;
         unsigned char *r = smem + G::oIc + (c * kMaxCars + d) * 16;
-        // degradation per lap of tyre age: compound rate x driver factor, reference :319-322
-        *reinterpret_cast<double *>(r) = P->comp_deg[c] * P->factor[d];
+        // degradation per lap of tyre age: compound rate x driver factor, reference :319-322; stored x 2^-16 (exact) so
+        // that it multiplies the age field of pk as it stands, (age << 16): one mask instead of a bit-field extract
+        *reinterpret_cast<double *>(r) = (P->comp_deg[c] * P->factor[d]) * kAgeFieldUnit;
         // pit word: threshold << 16, to be compared with (tyre age + 1) << 16 taken straight from pk (:454-465)
         *reinterpret_cast<uint32_t *>(r + 8) = (uint32_t)P->opt_laps[d * kCompStride + c] << 16;
         // DNF draw threshold, 32 bits: ceil(p 2^32) for p < 1 (reg_kernel_serves() keeps p >= 1 away from this kernel)
@@ -530,9 +578,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     auto load_slot = [&](uint32_t p, uint32_t lut_base) -> SlotIn {
         SlotIn r;
         r.fit = lds_ld<uint32_t>(((p & k3UsedMask) << 2) + lut_base);
-        r.la = last_of(p);
-        r.last = lds_ld<double>(G::oLast + r.la);
         const uint32_t id16 = (p >> 6) & 0x1F0u;                                  // 16 x driver
+        r.la = id16 * (uint32_t)(B / 2) + tid8;                                   // = driver x (B x 8) + tid8
+        r.last = lds_ld<double>(G::oLast + r.la);
         const uint32_t ic = id16 + ((p & k3CompMask) << 2);                       // 16 x (32 compound + driver)
         const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);
         r.var = vb.x;
@@ -580,55 +628,70 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     const uint32_t gw = (pos & 3) == 0 ? g0 : (pos & 3) == 1 ? g1 : (pos & 3) == 2 ? g2 : g3;
                     const double u = u32_to_unit(gw);
                     const uint32_t gcol = G::oGrid + (uint32_t)(pos * N) * 8u;           // [slot][driver], wave-uniform
-                    double p[N];
-                    double total = 0.0;                                                  // :119-123
-#pragma unroll
-                    for (int d = 0; d < N; ++d) {
-                        p[d] = ((remaining >> d) & 1u) ? lds_ld<double>(gcol + 8u * d) : 0.0;
-                        total = total + p[d];
-                    }
-                    const bool has_mass = total > 0;
-                    const double uniform_p = 1.0 / (double)n_remaining;                  // :127-130
-                    double prob_sum = 0.0;                                               // :125-133
-#pragma unroll
-                    for (int d = 0; d < N; ++d) {
-                        const double q = has_mass ? p[d] / total : uniform_p;
-                        p[d] = ((remaining >> d) & 1u) ? q : 0.0;
-                        prob_sum = prob_sum + p[d];
-                    }
-                    if (prob_sum > 0 && fabs(prob_sum - 1.0) > 1e-9) {                   // :134-135 (practically never)
-#pragma unroll
-                        for (int d = 0; d < N; ++d) p[d] = p[d] / prob_sum;
-                    }
-                    // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right')
+                    // Fast path, no division.  The reference normalises the column over the remaining drivers (:119-126),
+                    // numpy's choice() normalises the cumulative sums once more and takes the first entry above u: the
+                    // value compared with u is  R_d = fl(fl-sum_{j<=d} fl(p_j / total) / cdf_last),  within
+                    // (2 n + 6) 2^-53 (relative) of  S_d / S_n,  the exact partial sums of the column -- every term is
+                    // non-negative, so rounding errors stay relative and the common factor 1 / total cancels.  The partial
+                    // sums A_d computed here and uc = fl(u A_n) carry errors of the same size, so outside a band of 2^-40
+                    // around the threshold the comparison  A_d > u A_n  decides  R_d > u  whatever the roundings did; a draw
+                    // inside the band (about one in 10^10), a column without mass or a sum near the ends of binary64 takes
+                    // the exact path below, division by division.  (Placed drivers add +0.0 and repeat their predecessor's
+                    // partial sum: never the first one above.  u = 0 makes both bounds 0: the first positive sum.)
                     double acc = 0.0;
+                    double A[N];
 #pragma unroll
                     for (int d = 0; d < N; ++d) {
-                        acc = acc + p[d];
-                        p[d] = acc;
+                        const double pd = ((remaining >> d) & 1u) ? lds_ld<double>(gcol + 8u * d) : 0.0;
+                        acc = acc + pd;                                                  // :119-123 (the reference's `total`)
+                        A[d] = acc;
                     }
-                    const double cdf_last = acc;
-                    // searchsorted(cdf / cdf[-1], u, 'right'): the first driver with cdf[d] / cdf_last > u.  The
-                    // quotient is only formed when the answer is not already certain: fl(x / c) <= u for every
-                    // x <= fl(u c) (1 - 2^-50) and fl(x / c) > u for every x > fl(u c) (1 + 2^-50) (the three
-                    // roundings involved move a value by at most 2^-52 relative), so the division -- a dozen
-                    // instructions on this hardware -- runs only for a cdf entry within 2^-49 of the threshold.
-                    // The comparisons are strict: u = 0 (one draw in 2^32) makes both bounds 0, and a cdf entry of 0
-                    // -- the drivers placed before the first remaining one -- is not above it.
-                    const double uc = u * cdf_last;
-                    const double sure_le = uc * (1.0 - 0x1p-50), sure_gt = uc * (1.0 + 0x1p-50);
-                    uint32_t above = 0u, unsure = 0u;                                    // bit d: cdf[d] / cdf_last > u / not certain
+                    const double total = acc;
+                    const double uc = u * total;
+                    const double sure_gt = uc * (1.0 + 0x1p-40), sure_le = uc * (1.0 - 0x1p-40);
+                    uint32_t n_le = 0u, n_le_lo = 0u;                 // partial sums not above the upper / the lower bound
 #pragma unroll
                     for (int d = 0; d < N; ++d) {
-                        above |= p[d] > sure_gt ? (1u << d) : 0u;
-                        unsure |= (p[d] > sure_le && !(p[d] > sure_gt)) ? (1u << d) : 0u;
+                        n_le += A[d] > sure_gt ? 0u : 1u;
+                        n_le_lo += A[d] > sure_le ? 0u : 1u;
                     }
-                    if (unsure != 0u) {
+                    // (the sums are non-decreasing: the first one above the upper bound is entry n_le, and some sum lies
+                    //  inside the band iff the two counts differ)
+                    const bool exact_path = MCGP_GRID_EXACT || !(total > 0x1p-900 && total < 0x1p900) || n_le != n_le_lo || n_le >= (uint32_t)N;
+                    sel = n_le;
+                    if (__builtin_expect(MCGP_ANY(exact_path), 0)) {
+                        double p[N];
 #pragma unroll
-                        for (int d = 0; d < N; ++d)
-                            if ((unsure >> d) & 1u) above |= !(p[d] / cdf_last <= u) ? (1u << d) : 0u;
+                        for (int d = 0; d < N; ++d) p[d] = ((remaining >> d) & 1u) ? lds_ld<double>(gcol + 8u * d) : 0.0;
+                        const bool has_mass = total > 0;
+                        const double uniform_p = 1.0 / (double)n_remaining;                  // :127-130
+                        double prob_sum = 0.0;                                               // :125-133
+#pragma unroll
+                        for (int d = 0; d < N; ++d) {
+                            const double q = has_mass ? p[d] / total : uniform_p;
+                            p[d] = ((remaining >> d) & 1u) ? q : 0.0;
+                            prob_sum = prob_sum + p[d];
+                        }
+                        if (prob_sum > 0 && fabs(prob_sum - 1.0) > 1e-9) {                   // :134-135 (practically never)
+#pragma unroll
+                            for (int d = 0; d < N; ++d) p[d] = p[d] / prob_sum;
+                        }
+                        // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right'): the first driver
+                        // with cdf[d] / cdf_last > u.  The comparison is strict: a cdf entry of 0 -- the drivers placed
+                        // before the first remaining one -- is not above u = 0.
+                        double cdf = 0.0;
+#pragma unroll
+                        for (int d = 0; d < N; ++d) {
+                            cdf = cdf + p[d];
+                            p[d] = cdf;
+                        }
+                        const double cdf_last = cdf;
+                        uint32_t above = 0u;
+#pragma unroll
+                        for (int d = 0; d < N; ++d) above |= !(p[d] / cdf_last <= u) ? (1u << d) : 0u;
+                        const uint32_t sel_exact = above ? (uint32_t)__ffs((int)above) - 1u : 31u - (uint32_t)__clz((int)remaining);   // (never empty: cdf[-1] == 1 > u)
+                        sel = exact_path ? sel_exact : sel;
                     }
-                    sel = above ? (uint32_t)__ffs((int)above) - 1u : 31u - (uint32_t)__clz((int)remaining);   // (never empty: cdf[-1] == 1 > u)
                 }
                 if ((remaining >> sel) & 1u) { remaining &= ~(1u << sel); --n_remaining; }
                 lds_st<uint8_t>(grid_byte(pos), (uint8_t)sel);
@@ -680,8 +743,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // "strictly increasing times" be the sortedness test of the hot loop.
                 cum[i] = -(double)(i + 1) * 0x1p-1000;
             } else {
-                const uint32_t age = (p >> k3AgeShift) & 0x7FFu;
-                const double tire = (double)age * eff;
+                const double tire = (double)(p & k3AgeMask) * eff;                          // (eff x 2^-16)
                 const double fuel_effect = (110.0 - 110.0) * 0.03;
                 const double noise = 0.0 + vb.x * (double)z;
                 const double base_lap = vb.y + tire - fuel_effect + cdelta - 0.0 + noise;
@@ -710,6 +772,12 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             uint32_t c0l = c0, c1l = c1;
             pin(c0l);
             pin(c1l);
+            // Likewise the key: its ten round keys (seed + r x constant, twenty SGPRs) are worked out per lap from an opaque
+            // copy, on the scalar unit, instead of living across the whole kernel -- where the register allocator parks
+            // them in VGPR lanes and fetches each one back with a v_readlane (a VALU instruction) at every block.
+            uint32_t k0l = seed_lo, k1l = seed_hi;
+            pin_scalar(k0l);
+            pin_scalar(k1l);
             // The per-race constants of the lap body are read from the parameter block EVERY lap (scalar loads through
             // a pointer the optimiser cannot see through) instead of being held in registers across the whole race:
             // eight 64-bit values that would otherwise push as many lane masks and addresses out to scratch.
@@ -720,10 +788,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             // ---- race-interrupting events, :168-176 ----
             {
                 uint32_t e0, e1, e2, e3;
-                philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, e0, e1, e2, e3);
+                philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent, k0l, k1l, e0, e1, e2, e3);
                 if (MCGP_DUP & 16) {
                     uint32_t f0, f1, f2, f3;
-                    philox4x32_10(c0l ^ e0, c1l, (uint32_t)lap, kPurposeEvent, seed_lo, seed_hi, f0, f1, f2, f3);
+                    philox4x32_10(c0l ^ e0, c1l, (uint32_t)lap, kPurposeEvent, k0l, k1l, f0, f1, f2, f3);
                     if ((f0 | f1 | f2 | f3) == 0u) e0 = f0;     // never true in practice; keeps the block alive
                 }
                 const bool red = (uint64_t)e0 < t_red;
@@ -923,7 +991,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     for (int b = 0; b < MCGP_STEP_BATCH / 2; ++b) {
                         w[b][0] = w[b][1] = w[b][2] = w[b][3] = 0u;
                         if (i0 + 2 * b < N)
-                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | (uint32_t)((i0 >> 1) + b), seed_lo, seed_hi,
+                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | (uint32_t)((i0 >> 1) + b), k0l, k1l,
                                           w[b][0], w[b][1], w[b][2], w[b][3]);
                     }
                     float z[MCGP_STEP_BATCH];
@@ -945,7 +1013,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const double ahead_last = carry;                    // last lap of the running car ahead  :179-183
                         carry = active ? s.last : carry;
                         const uint32_t agef = p & k3AgeMask;
-                        const double tire = (double)(agef >> k3AgeShift) * s.eff;                   // :319-322
+                        const double tire = (double)agef * s.eff;                                   // :319-322 (eff x 2^-16)
                         const double drs_gain = s.drs;                                              // :327
                         const double noise = 0.0 + s.var * (double)z[j];                            // :330
                         const double clean = s.base + tire - fuel_effect + s.cdelta - drs_gain + noise;   // :332
@@ -986,9 +1054,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // uniform u = w 2^-32 is  w < 2^31  and  w < delta 2^31,  i.e.  w < thr = min(ceil(delta 2^31), 2^31)
                 // -- one integer per pair instead of a binary64 delta kept across the draw-word generation.
                 uint32_t thr[N];
-                uint32_t cand = 0u;
+                uint32_t ow[N];                  // first the W-plane address of the pair's draw word, then the word
+                // W-plane address of the NEXT attempt's word: a running sum over the candidates so far (row k of the plane
+                // holds the word of the lane's k-th attempt), advanced inside ovt_threshold by the compare that makes
+                // the pair a candidate
+                uint32_t row = tid4;
                 {
                     constexpr int H = MCGP_PACE_BATCH;
+                    const uint32_t row_stride = (uint32_t)(B * 4);
                     double pace_prev = 0.0;
 #pragma unroll
                     for (int h = 0; h < N; h += H) {
@@ -1009,31 +1082,35 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                             const int i = h + j;
                             if (i < N) {
                                 // a retired car's pace is NaN (table): its two pairs compare false below (:511)
-                                const double pace = pb[j] + (double)((pk[i] >> k3AgeShift) & 0x7FFu) * pd[j];
+                                const double pace = pb[j] + (double)(pk[i] & k3AgeMask) * pd[j];
                                 if (i > 0) {
                                     const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520 (x 2^31)
-                                    const bool c = dl > od31;                                       // :522
-                                    cand |= c ? (1u << i) : 0u;
-                                    const uint32_t t = min_u32(cvt_u32_f64_sat(ceil_f64(dl)), 0x80000000u);
-                                    thr[i] = c ? t : 0u;                                            // :523-524
+                                    // candidate iff dl > overtake_delta (:522); threshold min(ceil(dl), 2^31) (:523-524)
+                                    uint32_t next;
+                                    ovt_threshold(dl, od31, row, row_stride, thr[i], next);
+                                    ow[i] = row;
+                                    row = next;
                                 }
                                 pace_prev = pace;
                             }
                         }
                     }
                     thr[0] = 0u;
+                    ow[0] = 0u;
                 }
-                MCGP_STAT(0 + pass, cand != 0u);
-                if (cand == 0u) break;
+                const uint32_t words_end = row - tid4;          // = attempts of this lane x the row stride
+                MCGP_STAT(0 + pass, words_end != 0u);
+                if (words_end == 0u) break;
                 // ---- overtakes: draw words ----
                 // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4.  Up to 8 attempts per lane
                 // -- all but a few wave-passes in a thousand -- go through the W plane in one go: ow[i] = the word of the
                 // attempt at pair i.  A wave with a busier lane takes the general path, 8 attempts at a time, and leaves
                 // its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
-                const int n_cand = __popc(cand);
-                uint32_t ow[N];
-                ow[0] = 0u;
-                if (__builtin_expect(MCGP_ANY(n_cand > kWordRows), 0)) {
+                if (__builtin_expect(MCGP_ANY(words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
+                    // the candidate mask, from the addresses: a candidate advanced the running row
+                    uint32_t cand = 0u;
+#pragma unroll
+                    for (int i = 1; i < N; ++i) cand |= ((i + 1 < N ? ow[i + 1] : row) != ow[i]) ? (1u << i) : 0u;
                     uint32_t hits = 0u, rest = cand;
 #pragma unroll 1
                     for (int chunk = 0; rest != 0u; ++chunk) {
@@ -1044,8 +1121,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll 1
                         for (int b = 0; b < 2; ++b) {
                             uint32_t o0, o1, o2, o3;
-                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 2 * chunk + b), seed_lo,
-                                          seed_hi, o0, o1, o2, o3);
+                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 2 * chunk + b), k0l, k1l, o0, o1, o2, o3);
                             lds_st<uint32_t>(w_row(4 * b + 0), o0);
                             lds_st<uint32_t>(w_row(4 * b + 1), o1);
                             lds_st<uint32_t>(w_row(4 * b + 2), o2);
@@ -1068,21 +1144,22 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     }
                 } else {
                     uint32_t o0, o1, o2, o3;
-                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass), seed_lo, seed_hi, o0, o1, o2, o3);
+                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass), k0l, k1l, o0, o1, o2, o3);
                     lds_st<uint32_t>(w_row(0), o0);
                     lds_st<uint32_t>(w_row(1), o1);
                     lds_st<uint32_t>(w_row(2), o2);
                     lds_st<uint32_t>(w_row(3), o3);
-                    if (n_cand > 4) {
-                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 1), seed_lo, seed_hi, o0, o1, o2, o3);
+                    if (words_end > (uint32_t)(4 * B * 4)) {
+                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 1), k0l, k1l, o0, o1, o2, o3);
                         lds_st<uint32_t>(w_row(4), o0);
                         lds_st<uint32_t>(w_row(5), o1);
                         lds_st<uint32_t>(w_row(6), o2);
                         lds_st<uint32_t>(w_row(7), o3);
                     }
+                    // (a pair that is no candidate reads the word of the next attempt, or just past the plane: its
+                    //  threshold is 0)
 #pragma unroll
-                    for (int i = 1; i < N; ++i)
-                        ow[i] = lds_ld<uint32_t>(G::oW + (uint32_t)__popc(cand & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4);
+                    for (int i = 1; i < N; ++i) ow[i] = lds_ld<uint32_t>(G::oW + ow[i]);
                 }
                 // ---- overtakes: success test and write-back chain ----
                 // :523-531 in sorted order, each pair seeing the previous pair's mutation (Q15).  Branch-free: the
@@ -1091,15 +1168,15 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll
                 for (int i = 1; i < N; ++i) {
                     const bool hit = ow[i] < thr[i];
-                    const double nb = max_f64(cum[i - 1] - 0.1, 0.1);          // max(0.1, ahead - 0.1), :528
+                    const double nb = cum[i - 1] - 0.1;                        // max(0.1, ahead - 0.1), :528: reg_time_floor()
                     const double na = nb + 0.3;                                // :530
                     cum[i] = hit ? nb : cum[i];
                     cum[i - 1] = hit ? na : cum[i - 1];
                     any_succ |= hit;
                 }
                 MCGP_STAT(4 + pass, any_succ);
-                MCGP_STAT(8, __popc(cand));
-                MCGP_TRACE_PASS(local, lap, pass, __popc(cand));
+                MCGP_STAT(8, words_end / (uint32_t)(B * 4));
+                MCGP_TRACE_PASS(local, lap, pass, (int)(words_end / (uint32_t)(B * 4)));
                 if (!any_succ) break;
                 // ---- overtakes: re-sort ----
                 resort_after_overtakes<N>(cum, pk);     // sorted again for the next pass / _update_positions

@@ -586,7 +586,7 @@ def fuzz():
 def ref_stat(case, seeds, n_each):
     """Big-N reference histogram (one process per seed) for the statistical link."""
     import multiprocessing as mp
-    with mp.Pool(min(len(seeds), 8)) as pool:
+    with mp.Pool(min(len(seeds), int(os.environ.get('MCGP_STAT_PROCS', '8')))) as pool:
         hs = pool.starmap(_ref_stat_one, [(case, s, n_each) for s in seeds])
     np.savez_compressed(os.path.join(HERE, f"ref_stat_{case['name']}.npz"),
                         hist=np.sum(hs, axis=0), per_seed=np.array(hs), seeds=np.array(seeds),
@@ -687,8 +687,9 @@ def main():
         elo_season()
     if 'stat' in what:
         by = {c['name']: c for c in cases}
-        ref_stat(by['S60'], list(range(101, 109)), 25000)
-        ref_stat(by['S78'], list(range(201, 209)), 12500)
+        # 10^6 reference simulations each (round 4; rounds 1-3: 2x10^5 / 10^5): ~1.6 / 2.0 core-hours of the reference
+        ref_stat(by['S60'], list(range(101, 117)), 62500)
+        ref_stat(by['S78'], list(range(201, 217)), 62500)
 
 
 if __name__ == '__main__':

@@ -12,16 +12,25 @@ EMU_DIR = os.path.join(ROOT, 'tools', 'emu')
 LIB = os.path.join(EMU_DIR, 'libmcgp_emu.so')
 CSRC = os.path.join(ROOT, 'monte_carlo_gp_amd', 'csrc')
 
-_lib = None
+_libs = {}
+
+# named diagnostic variants of the host build: extra -D flags of csrc/race_kernel_reg.hip.h
+VARIANTS = {
+    None: [],
+    'grid_exact': ['-DMCGP_GRID_EXACT=1'],      # _sample_grid takes the exact (dividing) path for every draw
+}
 
 
-def build():
+def build(variant=None):
+    LIB = os.path.join(EMU_DIR, 'libmcgp_emu.so' if variant is None else f'libmcgp_emu_{variant}.so')
+    tag = '' if variant is None else '_' + variant
     srcs = [os.path.join(EMU_DIR, f) for f in ('emu_kernel.cpp', 'race_isa_host.h', 'hip/hip_runtime.h')]
     srcs += [os.path.join(CSRC, f) for f in ('race_kernel_reg.hip.h', 'race_common.hip.h', 'params_build.h', 'normal_table.h')]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         # four translation units (field sizes n % 4 == k) compiled side by side, then linked
         flags = ['-O1', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-I' + EMU_DIR, '-DEMU_PARTS=4']
-        objs = [os.path.join(EMU_DIR, f'emu_part{k}.o') for k in range(4)]
+        flags += VARIANTS[variant]
+        objs = [os.path.join(EMU_DIR, f'emu_part{k}{tag}.o') for k in range(4)]
         procs = [subprocess.Popen(['g++'] + flags + [f'-DEMU_PART={k}', '-c', '-o', objs[k],
                                                      os.path.join(EMU_DIR, 'emu_kernel.cpp')]) for k in range(4)]
         for pr in procs:
@@ -31,16 +40,15 @@ def build():
     return LIB
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(build())
+def lib(variant=None):
+    if variant not in _libs:
+        L = C.CDLL(build(variant))
         L.emu_run.restype = C.c_int
-        _lib = L
-    return _lib
+        _libs[variant] = L
+    return _libs[variant]
 
 
-def run(case, n_sims, seed, sim_offset=0, set_pop=None, fixed_grid=None):
+def run(case, n_sims, seed, sim_offset=0, set_pop=None, fixed_grid=None, variant=None):
     """(hist, orders) of the kernel source executed on the host for a golden-case dict."""
     from monte_carlo_gp_amd import RaceConfig
     from monte_carlo_gp_amd.simulation import RaceSimulator, _Problem, _dptr
@@ -56,7 +64,7 @@ def run(case, n_sims, seed, sim_offset=0, set_pop=None, fixed_grid=None):
     fg = None
     if fixed_grid is not None:
         fg = np.ascontiguousarray(fixed_grid, np.uint8).ctypes.data_as(C.c_void_p)
-    rc = lib().emu_run(C.byref(p.cfg), C.byref(p.drv), _dptr(g), C.c_uint32(n), C.c_uint64(n_sims),
+    rc = lib(variant).emu_run(C.byref(p.cfg), C.byref(p.drv), _dptr(g), C.c_uint32(n), C.c_uint64(n_sims),
                        C.c_uint64(sim_offset), C.c_uint64(seed), hist.ctypes.data_as(C.c_void_p),
                        orders.ctypes.data_as(C.c_void_p), fg, C.byref(err))
     if rc == -100:

@@ -108,3 +108,15 @@ def test_field_sizes_up_to_the_abi_maximum(n):
     ref = O.Problem(case).run(300, rng=O.RNG_PHILOX, seed=5, want_orders=True)
     hist, orders = K.run(case, 300, 5)
     assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+
+
+@pytest.mark.parametrize('name', ['S60', 'HET', 'N10'])
+def test_sample_grid_exact_path_equals_the_fast_path(name):
+    """_sample_grid decides `cdf[d] / cdf[-1] > u` without dividing when the draw is outside a 2^-40 band around the
+    threshold, and falls back to the reference's divisions otherwise: the build that divides for EVERY draw
+    (MCGP_GRID_EXACT) must give the same races, and both equal the oracle (reference :119-137)."""
+    case = O.load_case(name)
+    ref = O.Problem(case).run(400, rng=O.RNG_PHILOX, seed=7, want_orders=True)
+    _, fast = K.run(case, 400, 7)
+    _, exact = K.run(case, 400, 7, variant='grid_exact')
+    assert np.array_equal(fast, exact) and np.array_equal(exact, ref['orders'])

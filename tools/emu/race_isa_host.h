@@ -93,6 +93,12 @@ inline uint32_t next_ticket(uint32_t *, uint32_t tid, uint32_t turn, int waves) 
 inline void sched_fence() {}
 inline double ceil_f64(double x) { return std::ceil(x); }
 inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+inline void ovt_threshold(double dl, double od, uint32_t row, uint32_t stride, uint32_t &thr, uint32_t &next)
+{
+    const bool c = dl > od;
+    thr = c ? min_u32(cvt_u32_f64_sat(std::ceil(dl)), 0x80000000u) : 0u;
+    next = row + (c ? stride : 0u);
+}
 // threads of the emulated block run one after another: "any lane" is this thread alone (both paths behind an
 // MCGP_ANY test compute the same results, so which one a thread takes does not matter); EMU_FORCE_ANY=1 sends every
 // thread down the "some lane needs it" path, which a single-thread view would otherwise reach only rarely
@@ -103,6 +109,7 @@ inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #endif
 inline void pin(uint32_t &) {}
 inline void pin(double &) {}
+inline void pin_scalar(uint32_t &) {}
 template <typename T>
 inline void pin_ptr(const T *&) {}
 inline float4 lds_ld_float4(uint32_t addr) { return lds_ld<float4>(addr); }
