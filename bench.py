@@ -22,7 +22,7 @@ The JSON line printed by rank 0 carries, besides the contract fields,
                  utilisation on this hardware (it reads 1.07 for this kernel); `traffic` = HBM bytes per
                  launch from the PMC passes; roofline.hbm_nominal = the 20 algorithmic bytes per simulation
                  against the 8 TB/s HBM peak -- evidence that the path is NOT memory bound.  Counters are quoted only
-                 when profiles/r3_counters.json carries the source hash of the loaded library (else null, reason in
+                 when profiles/r4_counters.json carries the source hash the loaded binary reports (else null, reason in
                  roofline.counters_note)
   workloads.S78  BASELINE configs[2] (78-lap Monaco parameters), three steps in the same run        (N = 1 only)
   orders_mode    the same workload with the 20 B per simulation actually written                    (N = 1 only)
@@ -51,7 +51,8 @@ VALU_PEAK_TINST = 1024 * 2.4e9 / 2 / 1e12   # 256 CUs x 4 SIMD-32, one wave64 VA
 # rate for every instruction; with the 2-cycle class in the mix it overshoots 1 -- 1.07 for the S60 kernel -- and is
 # quoted as `valu_busy_profiled` for reference only.)
 VALU_PEAK_TINST_4CYCLE = 1024 * 2.4e9 / 4 / 1e12
-COUNTERS_FILE = 'r3_counters.json'
+COUNTERS_FILE = 'r4_counters.json'
+MIX_FILE = 'r4_valu_mix.json'
 
 
 def load_workload(name):
@@ -165,7 +166,7 @@ def cpu_baseline(case_name, seconds=12.0, all_core_seconds=8.0):
 
 def profiled_counters(workload, per_gpu, lib_overridden):
     """PMC-derived figures kept under profiles/ (rocprofv3 --pmc passes, tools/summarize_profiles.py), quoted
-    ONLY when the file is stamped with the hash of the kernel sources the loaded library was built from."""
+    ONLY when the file is stamped with the source hash the LOADED binary reports (mcgp_build_hash())."""
     from monte_carlo_gp_amd import _native as N
     path = os.path.join(ROOT, 'profiles', COUNTERS_FILE)
     if lib_overridden:
@@ -175,12 +176,14 @@ def profiled_counters(workload, per_gpu, lib_overridden):
             pc = json.load(f)
     except (OSError, ValueError) as e:
         return None, f'no usable {os.path.relpath(path, ROOT)}: {e}'
-    if pc.get('source_hash') != N.source_hash():
-        return None, (f"profiles/r3_counters.json was taken from sources {pc.get('source_hash')}, "
-                      f'the loaded library is built from {N.source_hash()}: re-profile')
+    # the identity compiled INTO the mapped binary (mcgp_build_hash()), not a hash of the files on disk: _native.lib()
+    # has already refused a binary whose identity is not that of the tree
+    if pc.get('source_hash') != N.build_hash():
+        return None, (f"profiles/{COUNTERS_FILE} was taken from a binary built from sources {pc.get('source_hash')}, "
+                      f'the loaded library reports {N.build_hash()}: re-profile')
     w = pc.get('workloads', {}).get(workload)
     if not w or w.get('sims_per_launch') != per_gpu:
-        return None, f'profiles/r3_counters.json has no {workload} entry at {per_gpu} simulations per launch'
+        return None, f'profiles/{COUNTERS_FILE} has no {workload} entry at {per_gpu} simulations per launch'
     return w, None
 
 
@@ -302,6 +305,7 @@ def main():
                     kernel_ms=float(np.mean(kernel_ms)), kernel=lib.mcgp_last_kernel_name(local_rank).decode(),
                     launch={'grid': g.value, 'block': b.value, 'lds_bytes': lds.value})
 
+    t_gpu0 = time.perf_counter()
     r = run_workload(args.workload, args.steps, args.warmup, with_orders=args.orders)
     if rank == 0:
         n, L, kavg_ms, hist = r['n'], r['L'], r['kernel_ms'], r['hist']
@@ -322,12 +326,25 @@ def main():
                          'active_lane_ratio': pc.get('active_lane_ratio'), 'waves_per_simd': pc.get('waves_per_simd'),
                          'scratch_bytes_per_lane': int(pc.get('kernel', {}).get('Scratch_Size', 0) or 0),
                          'source_hash': pc.get('source_hash'),
-                         'counters': 'profiles/r3_counters.json (rocprofv3 --pmc, tools/profile_r3.sh), same source hash as the loaded library'})
+                         'counters': f'profiles/{COUNTERS_FILE} (rocprofv3 --pmc, tools/profile_r4.sh), stamped with the '
+                                     'source hash the loaded binary reports (mcgp_build_hash)'})
+            # Lane-level view of the same counters.  A wave-instruction issues for 64 lanes whether they
+            # are masked or not; weighting by the measured share of active lanes gives the USEFUL lane-operations and
+            # their fraction of the lane-level peak (64 lanes x the 2-cycle issue rate).
+            alr = pc.get('active_lane_ratio')
+            if alr:
+                lane_peak = VALU_PEAK_TINST * 1e12 * 64
+                roof.update({'lane_ops_per_sim': insts * 64 * alr / per_gpu,
+                             'frac_useful_lanes': rate * 1e12 * 64 * alr / lane_peak,
+                             'lane_note': 'lane_ops_per_sim = SQ_INSTS_VALU x 64 x active_lane_ratio / simulations (measured); '
+                                          "frac_useful_lanes = frac x active_lane_ratio.  SURVEY.md 8(d)'s a-priori figures "
+                                          '(5.6e5 lane-ops per simulation, 3.9e13 lane-ops/s peak) are superseded by these '
+                                          'measurements: applied to the measured rate they would give a fraction above 1'})
             # the ceiling for THIS kernel's instruction mix: measured issue cost per class (tools/valu_peak.hip: binary64
             # and VOP3 / 64-bit integer instructions ~4.2 cycles per wave64 instruction, VOP1 / VOP2 32-bit ones ~2.25)
             # weighted by the class shares of the lap loop (tools/valu_mix.py), same source hash
             try:
-                with open(os.path.join(ROOT, 'profiles', 'r3_valu_mix.json')) as f:
+                with open(os.path.join(ROOT, 'profiles', MIX_FILE)) as f:
                     mix = json.load(f)
                 if mix.get('source_hash') == pc.get('source_hash'):
                     roof.update({'peak_for_instruction_mix': mix['peak_T_wave_instructions_per_s_for_this_mix'],
@@ -388,9 +405,25 @@ def main():
                               'kernel_ms_avg': wo['kernel_ms'], 'bytes_per_launch': bytes_written,
                               'write_gb_per_s': bytes_written / (wo['kernel_ms'] * 1e-3) / 1e9,
                               'frac_of_hbm_peak': bytes_written / (wo['kernel_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    gpu_seconds = time.perf_counter() - t_gpu0           # every GPU leg of this run: timed steps, warm-up, side lines
+    # which device each rank ran on: N ranks on N DISTINCT GPUs is a fact of the run, printed, not an assumption
+    props = torch.cuda.get_device_properties(dev)
+    me = {'rank': rank, 'local_device': local_rank, 'name': props.name,
+          'uuid': str(getattr(props, 'uuid', '')), 'pci_bus_id': getattr(props, 'pci_bus_id', None),
+          'pci_device_id': getattr(props, 'pci_device_id', None), 'pci_domain_id': getattr(props, 'pci_domain_id', None)}
+    devices = [me]
+    if grouped:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
     if rank == 0:
+        out['devices'] = devices
+        out['distinct_devices'] = len({(d['uuid'], d['pci_bus_id'], d['pci_domain_id']) for d in devices})
+        out['library'] = {'build_hash': N.build_hash(), 'path': os.environ.get('MCGP_LIB') or N.LIB_PATH}
+        out['gpu_seconds'] = gpu_seconds
         if world == 1 and not args.no_cpu_baseline:
+            t_cpu0 = time.perf_counter()
             out['cpu_baseline'] = cpu_baseline(args.workload)
+            out['cpu_baseline_seconds'] = time.perf_counter() - t_cpu0
         print(json.dumps(out), flush=True)
     if grouped:
         dist.barrier()

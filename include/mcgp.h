@@ -87,6 +87,12 @@ typedef struct mcgp_drivers {
 } mcgp_drivers;
 
 int32_t mcgp_abi_version(void);
+/* Identity of the binary: the hash of the sources it was compiled from (csrc/source_hash.py: sha256 over the .hip and .h
+ * files of csrc/, the Makefile and this header, 16 hex digits; "unknown" for a build outside the Makefile).  The host
+ * binding computes the same hash from the tree and refuses a library that carries another one; bench.py quotes
+ * profiled counters only when they were taken from a binary with this hash.  The file also holds the text
+ * "MCGP_BUILD_HASH=<hash>", readable without loading the library. */
+const char *mcgp_build_hash(void);
 int32_t mcgp_device_count(void);          /* number of HIP devices, 0 if none */
 const char *mcgp_last_error(void);        /* thread-local, never NULL */
 

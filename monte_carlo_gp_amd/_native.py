@@ -44,28 +44,46 @@ class McgpDrivers(C.Structure):
                 ('base_pace', 'tire_deg', 'tire_deg_pit', 'variance', 'team_dnf', 'lap_dnf')]
 
 
+def _load_source_hash_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_mcgp_source_hash', os.path.join(CSRC, 'source_hash.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _sources():
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
-            if f.endswith(('.hip', '.h')) or f == 'Makefile']
-    srcs.append(os.path.join(os.path.dirname(_PKG), 'include', 'mcgp.h'))
-    return srcs
-
-
-def _stale():
-    return (not os.path.exists(LIB_PATH)
-            or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in _sources()))
+    return _load_source_hash_module().sources()
 
 
 def source_hash():
-    """sha256 over the kernel sources and the Makefile (sorted by name): ties a profile under profiles/ to
-    the code it was taken from (bench.py quotes counters only when this matches)."""
-    import hashlib
-    h = hashlib.sha256()
-    for path in sorted(_sources(), key=os.path.basename):
-        h.update(os.path.basename(path).encode() + b'\0')
+    """Identity of the kernel sources in this tree (csrc/source_hash.py): the Makefile compiles the same value into
+    libmcgp_hip.so, and profiles under profiles/ are stamped with it."""
+    return _load_source_hash_module().source_hash()
+
+
+_MARKER = b'MCGP_BUILD_HASH='
+
+
+def file_build_hash(path):
+    """The source hash a library FILE was compiled from, read from its marker string without loading it
+    (None: no such file, or a binary without the marker)."""
+    try:
         with open(path, 'rb') as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(_MARKER)
+    if i < 0:
+        return None
+    j = blob.find(b'\0', i)
+    return blob[i + len(_MARKER):j].decode('ascii', 'replace')
+
+
+def _stale():
+    """The library is stale unless it carries the hash of the sources beside it (contents, not time stamps: a stale
+    binary with a newer mtime is still stale)."""
+    return file_build_hash(LIB_PATH) != source_hash()
 
 
 def build(force=False):
@@ -73,9 +91,14 @@ def build(force=False):
 
     One builder per node: an exclusive flock serialises the ranks of a torch.distributed.run launch (the
     first one in builds, the others find the library up to date), make relinks through a temporary file
-    renamed into place, and an up-to-date tree is a no-op.  Runs before any HIP call of this process."""
+    renamed into place, and an up-to-date tree is a no-op (make is incremental).  Runs before any HIP call of
+    this process.  MCGP_NO_BUILD=1 forbids building (deployments without hipcc, and the staleness test): a stale
+    library is then refused instead of rebuilt."""
     if not (force or _stale()):
         return LIB_PATH
+    if os.environ.get('MCGP_NO_BUILD') == '1':
+        raise McgpError(-1, f'{LIB_PATH} is stale (built from sources {file_build_hash(LIB_PATH)}, the tree is '
+                            f'{source_hash()}) and MCGP_NO_BUILD=1 forbids rebuilding it')
     import fcntl
     os.makedirs(os.path.join(CSRC, 'build'), exist_ok=True)
     with open(os.path.join(CSRC, 'build', '.lock'), 'w') as lock:
@@ -83,9 +106,11 @@ def build(force=False):
         try:
             if force or _stale():
                 subprocess.check_call(['make', '-C', CSRC, '-s'] + (['-B'] if force else []))
-                os.utime(LIB_PATH)        # newer than every source even if make found nothing to do
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
+    if _stale():
+        raise McgpError(-1, f'{LIB_PATH} still carries source hash {file_build_hash(LIB_PATH)} after make; the tree '
+                            f'is {source_hash()}')
     return LIB_PATH
 
 
@@ -142,7 +167,7 @@ def assert_single_hip_runtime():
 
 _lib = None
 
-EXPORTS = ('mcgp_abi_version', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
+EXPORTS = ('mcgp_abi_version', 'mcgp_build_hash', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
            'mcgp_simulate_race', 'mcgp_grid_probs', 'mcgp_run_from_ratings', 'mcgp_last_kernel_ms',
            'mcgp_stream_kernel_ms', 'mcgp_elo_season',
            'mcgp_last_launch_info', 'mcgp_last_kernel_name')
@@ -159,6 +184,14 @@ def lib():
         _bind_hip_runtime()
         L = C.CDLL(path)
         assert_single_hip_runtime()
+        if hasattr(L, 'mcgp_build_hash'):
+            L.mcgp_build_hash.restype = C.c_char_p
+        if not os.environ.get('MCGP_LIB'):
+            # the binary that is MAPPED must be the one whose file was checked (a rebuild renames a new file into place)
+            loaded = L.mcgp_build_hash().decode() if hasattr(L, 'mcgp_build_hash') else None
+            if loaded != source_hash():
+                raise McgpError(-1, f'{path} was compiled from sources {loaded}, the tree is {source_hash()}: refusing '
+                                    'to run a stale kernel')
         L.mcgp_abi_version.restype = C.c_int32
         L.mcgp_device_count.restype = C.c_int32
         L.mcgp_last_error.restype = C.c_char_p
@@ -200,6 +233,12 @@ def lib():
             raise McgpError(-1, f'ABI version {L.mcgp_abi_version()} != {ABI_VERSION}')
         _lib = L
     return _lib
+
+
+def build_hash():
+    """Source hash compiled into the library this process has loaded (mcgp_build_hash())."""
+    L = lib()
+    return L.mcgp_build_hash().decode() if hasattr(L, 'mcgp_build_hash') else None
 
 
 def check(rc):

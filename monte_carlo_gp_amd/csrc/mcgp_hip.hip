@@ -489,6 +489,15 @@ extern "C" {
 
 int32_t mcgp_abi_version(void) { return MCGP_ABI_VERSION; }
 
+// Identity of the sources this binary was compiled from (csrc/source_hash.py, passed in by the Makefile).  The same
+// value sits in the file as the text after "MCGP_BUILD_HASH=", so that a loader can read it without mapping the library.
+#ifndef MCGP_SOURCE_HASH
+#define MCGP_SOURCE_HASH "unknown"
+#endif
+extern const char mcgp_build_hash_marker[];
+__attribute__((used)) const char mcgp_build_hash_marker[] = "MCGP_BUILD_HASH=" MCGP_SOURCE_HASH;
+const char *mcgp_build_hash(void) { return mcgp_build_hash_marker + sizeof("MCGP_BUILD_HASH=") - 1; }
+
 int32_t mcgp_device_count(void) { return device_count_nothrow(); }
 
 const char *mcgp_last_error(void) { return g_err.c_str(); }

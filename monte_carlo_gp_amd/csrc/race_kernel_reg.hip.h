@@ -990,14 +990,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll
                     for (int b = 0; b < MCGP_STEP_BATCH / 2; ++b) {
                         w[b][0] = w[b][1] = w[b][2] = w[b][3] = 0u;
-                        if (i0 + 2 * b < N)
+                        if (i0 + 2 * b < N && !((MCGP_SKIP & 128) && b > 0))
                             philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | (uint32_t)((i0 >> 1) + b), k0l, k1l,
                                           w[b][0], w[b][1], w[b][2], w[b][3]);
                     }
                     float z[MCGP_STEP_BATCH];
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j)
-                        z[j] = (i0 + j < N) ? normal_from_u32_rows(w[j >> 1][2 * (j & 1) + 1], norm_row) : 0.0f;
+                        z[j] = (i0 + j < N) ? normal_from_u32_rows((MCGP_SKIP & 128) ? w[0][j & 3] : w[j >> 1][2 * (j & 1) + 1], norm_row) : 0.0f;
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
                         const int i = i0 + j;
@@ -1008,7 +1008,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const bool active = !(p & k3Dnf);                   // running at the start of the lap
                         // this lap's DNF draw (:194-197): u < p  <=>  word < ceil(p 2^32)  (p < 1 here: a field with a
                         // driver who retires with certainty every lap is served by the generic kernel, see mcgp_hip.hip)
-                        const bool dnf_hit = wd < s.tdnf;
+                        const bool dnf_hit = (MCGP_SKIP & 128) ? false : wd < s.tdnf;
                         const bool run = active && !dnf_hit;
                         const double ahead_last = carry;                    // last lap of the running car ahead  :179-183
                         carry = active ? s.last : carry;

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mcgp_abi_version() == 1
+    assert L.mcgp_abi_version() == N.ABI_VERSION
     assert L.mcgp_device_count() >= 0
 
 
@@ -147,3 +147,38 @@ def test_one_hip_runtime_whichever_is_loaded_first():
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.split() == ['2', '0'], out.stdout          # the failure mode, detected
+
+
+def test_a_stale_library_is_refused(tmp_path):
+    """the binary carries the hash of the sources it was compiled from (mcgp_build_hash(), and the
+    marker MCGP_BUILD_HASH=... in the file) and the binding checks CONTENTS, not time stamps.  A library built from
+    other sources -- here: a copy of the real one with another hash patched in, and the newest mtime of all -- is
+    refused before anything is launched: with MCGP_NO_BUILD=1 by build(), and, if it is mapped behind the binding's
+    back, by lib() itself."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    N.lib()                                                  # the real library exists and is current
+    assert N.file_build_hash(N.LIB_PATH) == N.source_hash() == N.build_hash()
+    stale = tmp_path / 'libmcgp_hip.so'
+    shutil.copy(N.LIB_PATH, stale)
+    blob = stale.read_bytes()
+    marker = b'MCGP_BUILD_HASH=' + N.source_hash().encode()
+    assert blob.count(marker) >= 1
+    stale.write_bytes(blob.replace(marker, b'MCGP_BUILD_HASH=' + b'0123456789abcdef'))
+    os.utime(stale)                                          # newer than every source: an mtime test would accept it
+    assert N.file_build_hash(str(stale)) == '0123456789abcdef'
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from monte_carlo_gp_amd import _native as N\n"
+            "N.LIB_PATH = sys.argv[1]\n"
+            "mode = sys.argv[2]\n"
+            "if mode == 'behind':\n    N._stale = lambda: False\n"      # pretend the file check passed
+            "try:\n    N.lib(); print('loaded')\n"
+            "except N.McgpError as e:\n    print('refused:', e)\n") % (os.path.dirname(N._PKG),)
+    env = dict({k: v for k, v in os.environ.items() if k != 'MCGP_LIB'}, MCGP_NO_BUILD='1')
+    for mode in ('file', 'behind'):
+        out = subprocess.run([sys.executable, '-c', code, str(stale), mode], env=env, capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.startswith('refused:') and '0123456789abcdef' in out.stdout, (mode, out.stdout)
