@@ -17,7 +17,7 @@ def test_source_hash_covers_the_kernel_sources(tmp_path):
     assert len(h) == 16 and h == N.source_hash()
     names = {os.path.basename(p) for p in N._sources()}
     assert {'race_kernel_reg.hip.h', 'race_common.hip.h', 'race_isa.hip.h', 'mcgp_hip.hip', 'params_build.h',
-            'frontend_exp.h', 'normal_table.h', 'Makefile', 'mcgp.h'} <= names
+            'frontend_exp.h', 'normal_table.h', 'Makefile', 'mcgp.h', 'source_hash.py', 'reg_inst.hip'} <= names
 
 
 def test_profiled_counters_are_refused_for_other_sources(tmp_path, monkeypatch):
@@ -26,11 +26,12 @@ def test_profiled_counters_are_refused_for_other_sources(tmp_path, monkeypatch):
     w, why = bench.profiled_counters('S60', 10_000_000, False)
     assert w is None and 'no usable' in why
     doc = {'source_hash': 'deadbeefdeadbeef', 'workloads': {'S60': {'sims_per_launch': 10_000_000, 'SQ_INSTS_VALU': 1.0}}}
-    (tmp_path / 'profiles' / 'r3_counters.json').write_text(json.dumps(doc))
+    (tmp_path / 'profiles' / bench.COUNTERS_FILE).write_text(json.dumps(doc))
     w, why = bench.profiled_counters('S60', 10_000_000, False)
     assert w is None and 're-profile' in why
-    doc['source_hash'] = N.source_hash()
-    (tmp_path / 'profiles' / 'r3_counters.json').write_text(json.dumps(doc))
+    doc['source_hash'] = N.build_hash()            # what the LOADED binary reports (= the tree's hash, or lib() refuses)
+    assert N.build_hash() == N.source_hash()
+    (tmp_path / 'profiles' / bench.COUNTERS_FILE).write_text(json.dumps(doc))
     w, why = bench.profiled_counters('S60', 10_000_000, False)
     assert why is None and w['SQ_INSTS_VALU'] == 1.0
     assert bench.profiled_counters('S60', 10_000_000, True)[0] is None              # MCGP_LIB set
