@@ -154,6 +154,8 @@ struct DeviceCtx {
         hipStream_t stream = nullptr;
         hipEvent_t start = nullptr, stop = nullptr;
         uint32_t *d_ticket = nullptr;       // the work counter of this stream's launches (race_kernel_reg.hip.h, phase 2)
+        uint32_t *d_retire = nullptr;       // the lanes' retirement lists of this stream's launches (grow-only)
+        size_t retire_bytes = 0;
         bool used = false;
         uint64_t seq = 0;
     } timer[kStreamTimers];
@@ -212,6 +214,7 @@ void release_ctx(DeviceCtx &c)
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
         if (t.d_ticket) (void)hipFree(t.d_ticket);
+        if (t.d_retire) (void)hipFree(t.d_retire);
         t = DeviceCtx::Timer{};
     }
     c.last_timer = -1;
@@ -272,7 +275,7 @@ int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
 }
 
 using KernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, uint32_t, unsigned long long *,
-                          uint8_t *, const uint8_t *, uint32_t, uint32_t *);
+                          uint8_t *, const uint8_t *, uint32_t, uint32_t *, uint32_t *);
 
 }  // namespace
 
@@ -281,7 +284,7 @@ using KernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, u
 namespace mcgp {
 #define X(N_) extern template __global__ void race_kernel_reg<N_>(const KParams *, uint64_t, uint64_t, uint32_t, uint32_t, \
                                                                   unsigned long long *, uint8_t *, const uint8_t *, uint32_t, \
-                                                                  uint32_t *);
+                                                                  uint32_t *, uint32_t *);
 MCGP_REG_SIZES(X)
 #undef X
 }  // namespace mcgp
@@ -294,7 +297,7 @@ KernelFn select_kernel(const mcgp::KParams &kp, bool *is_reg)
     const uint32_t n = (uint32_t)kp.n;
     const char *force = std::getenv("MCGP_FORCE_GENERIC");
     if (force && force[0] == '1') return &mcgp::race_kernel;
-    if (!mcgp::reg_kernel_serves(kp)) return &mcgp::race_kernel;      // a DNF probability >= 1: 33-bit threshold
+    if (!mcgp::reg_kernel_serves(kp)) return &mcgp::race_kernel;      // lap times near zero, values near the ends of binary64
     switch (n) {
 #define X(N_) case N_: *is_reg = true; return &mcgp::race_kernel_reg<N_>;
         MCGP_REG_SIZES(X)
@@ -447,11 +450,27 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
         const uint64_t unit = is_reg ? 64u : block;
         const uint64_t n_batches = (m + unit - 1) / unit;
-        if (is_reg) HIP_TRY(hipMemsetAsync(c.timer[ti].d_ticket, 0, sizeof(uint32_t), stream));
+        if (is_reg) {
+            HIP_TRY(hipMemsetAsync(c.timer[ti].d_ticket, 0, sizeof(uint32_t), stream));
+            // the lanes' retirement lists: scratch of the launch, (n + 1) words per lane, kept per stream and grown on
+            // demand (a launch of this stream that still uses the old buffer has been enqueued before the free, which
+            // the runtime orders behind it)
+            const size_t want = mcgp::reg_retire_ws_bytes(kp.n, (size_t)grid * block);
+            if (want > c.timer[ti].retire_bytes) {
+                if (c.timer[ti].d_retire) {
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    (void)hipFree(c.timer[ti].d_retire);
+                }
+                c.timer[ti].d_retire = nullptr;
+                c.timer[ti].retire_bytes = 0;
+                HIP_TRY(hipMalloc(&c.timer[ti].d_retire, want));
+                c.timer[ti].retire_bytes = want;
+            }
+        }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
                            (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
                            d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
-                           (uint32_t)n_batches, c.timer[ti].d_ticket);
+                           (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c.timer[ti].stop, stream));

@@ -15,6 +15,32 @@ constexpr uint32_t kPurposeGrid = 0u << 16;
 constexpr uint32_t kPurposeEvent = 1u << 16;
 constexpr uint32_t kPurposeCar = 2u << 16;
 constexpr uint32_t kPurposeOvt = 3u << 16;
+constexpr uint32_t kPurposeRetire = 4u << 16;
+
+// ---- retirements of laps >= 2 (reference :190-197), drawn once per race ----
+// The reference retires a running car on a lap if a fresh uniform is below the driver's per-lap probability p; the lap of
+// the first success is geometric.  Here it comes from ONE word w per driver and race (counter {sim, 0, RETIRE | d >> 2},
+// word d & 3): with t = ceil(p 2^32) (as for every Bernoulli draw of the path) and q = 2^32 - t, the car survives lap k
+// (k = 2, 3, ..) iff  w < S_k,  S_2 = q,  S_{k+1} = floor(S_k q / 2^32)  -- integer arithmetic, the same on every
+// device and in the oracle.  S is non-increasing, so the retirement lap is 2 + the number of laps survived; t = 0 never
+// retires, t = 2^32 (p >= 1) retires on lap 2.  P(retire on lap k | running) = 1 - S_k / S_{k-1} = p to within 2^-32 / S,
+// the resolution every other draw of the path has.
+__host__ __device__ inline uint32_t retire_next_threshold(uint32_t S, uint32_t q)
+{
+    return (uint32_t)(((uint64_t)S * (uint64_t)q) >> 32);
+}
+// the lap (2 .. L), or 0 for "not in this race"
+__host__ __device__ inline uint32_t draw_retirement_lap(uint32_t w, uint64_t t, int L)
+{
+    if (t == 0ull) return 0u;
+    const uint32_t q = (uint32_t)(4294967296ull - t);
+    uint32_t S = q;
+    for (int k = 2; k <= L; ++k) {
+        if (!(w < S)) return (uint32_t)k;
+        S = retire_next_threshold(S, q);
+    }
+    return 0u;
+}
 
 // pk word layout
 constexpr uint32_t kAgeMask = 0x3FFu;          // tyre age; lap of retirement once dnf is set
@@ -52,7 +78,7 @@ constexpr size_t kSharedTableBytes =
     + kMaxCars * kCompStride * 2   // opt_laps
     + 2 * kCompStride * 8       // comp_deg, comp_delta
     + kMaxCars * kMaxCars * 4;  // histogram
-__host__ __device__ constexpr size_t per_thread_lds_bytes(int n) { return (size_t)n * (8 + 8 + 4 + 1); }
+__host__ __device__ constexpr size_t per_thread_lds_bytes(int n) { return (size_t)n * (8 + 8 + 4 + 1 + 2); }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1,

@@ -22,6 +22,14 @@ __device__ __forceinline__ double max_f64(double a, double b)
     return r;
 }
 
+// max(|a|, b): the magnitude of a through the instruction's source modifier (no extra instruction)
+__device__ __forceinline__ double max_abs_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Compare-exchange on the time alone, the payload word following its time: after it (ca, pa) holds the smaller
 // time.  Equal times are left as they are (stable).  One statement so that the two f64 selects sit between the
 // compare and the payload selects: the v_cmp -> v_cndmask (VCC) dependency needs two wait states, and the compiler
@@ -291,6 +299,11 @@ template <typename T>
 __device__ __forceinline__ void lds_st(uint32_t addr, T v)
 {
     *reinterpret_cast<MCGP_LDS T *>(addr) = v;
+}
+// OR into a word of LDS without reading it back: one ds_or_b32, nothing to wait for
+__device__ __forceinline__ void lds_or_u32(uint32_t addr, uint32_t bits)
+{
+    (void)__hip_atomic_fetch_or(reinterpret_cast<MCGP_LDS uint32_t *>(addr), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 __device__ __forceinline__ float4 lds_ld_float4(uint32_t addr)          // one ds_read_b128
 {

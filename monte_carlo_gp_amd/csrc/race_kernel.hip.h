@@ -35,12 +35,14 @@ struct Rows {
     double *last;
     uint32_t *pk;
     uint8_t *ord;
+    uint16_t *out;   // lap of the driver's retirement (laps >= 2), 0 = not in this race: drawn once per race
     int B;      // row stride (threads per block)
     int tid;
     __device__ __forceinline__ double &Cum(uint32_t d) const { return cum[d * B + tid]; }
     __device__ __forceinline__ double &Last(uint32_t d) const { return last[d * B + tid]; }
     __device__ __forceinline__ uint32_t &Pk(uint32_t d) const { return pk[d * B + tid]; }
     __device__ __forceinline__ uint8_t &Ord(int i) const { return ord[i * B + tid]; }
+    __device__ __forceinline__ uint16_t &Out(uint32_t d) const { return out[d * B + tid]; }
 };
 
 __device__ __forceinline__ uint32_t gpos_of(uint32_t pk) { return (pk >> kGposShift) & 31u; }
@@ -102,7 +104,8 @@ __global__ void __launch_bounds__(512)
 race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
             uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
             uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_batches,
-            uint32_t * /*ticket: the register kernel's work counter; batches are dealt out by block index here*/)
+            uint32_t * /*ticket: the register kernel's work counter; batches are dealt out by block index here*/,
+            uint32_t * /*retire_ws: the register kernel's retirement lists; an LDS row per driver here*/)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -128,6 +131,7 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
     s.last = s.cum + (size_t)n * B;
     s.pk = reinterpret_cast<uint32_t *>(s.last + (size_t)n * B);
     s.ord = reinterpret_cast<uint8_t *>(s.pk + (size_t)n * B);
+    s.out = reinterpret_cast<uint16_t *>(s.ord + (size_t)n * B);
     s.B = B;
     s.tid = tid;
 
@@ -246,6 +250,17 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
         sort_by_time(s, n);
         update_positions(s, n, false, dirty_thr);
 
+        // ================= retirements of laps 2..L (:190-197), drawn once per race: race_common.hip.h =================
+        {
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            for (int d = 0; d < n; ++d) {
+                if ((d & 3) == 0)
+                    philox4x32_10(c0, c1, 0u, kPurposeRetire | (uint32_t)(d >> 2), seed_lo, seed_hi, r0, r1, r2, r3);
+                const uint32_t rw = (d & 3) == 0 ? r0 : (d & 3) == 1 ? r1 : (d & 3) == 2 ? r2 : r3;
+                s.Out(d) = (uint16_t)draw_retirement_lap(rw, t_dnf[d], L);
+            }
+        }
+
         // ================= laps 2..L, reference :166-228 =================
         int drs_disabled_until = 0;
         for (int lap = 2; lap <= L; ++lap) {
@@ -310,14 +325,15 @@ race_kernel(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                     if (pk & kDnf) continue;
                     const double ahead_last = carry;
                     carry = s.Last(d);
-                    uint32_t w0, w1, w2, w3;
-                    // draws are addressed by the car's place i in the field order: one block serves places 2j and 2j+1
-                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | ((uint32_t)i >> 1), seed_lo, seed_hi, w0, w1, w2, w3);
-                    if (i & 1) { w0 = w2; w1 = w3; }
-                    if ((uint64_t)w0 < t_dnf[d]) {                  // :194-197
+                    if ((int)s.Out(d) == lap) {                     // :194-197, drawn before the race
                         s.Pk(d) = (pk & ~kAgeMask) | kDnf | (uint32_t)lap;
                         continue;
                     }
+                    uint32_t w0, w1, w2, w3;
+                    // the lap noise is addressed by the car's place i in the field order: one block serves places 4j .. 4j+3
+                    philox4x32_10(c0, c1, (uint32_t)lap, kPurposeCar | ((uint32_t)i >> 2), seed_lo, seed_hi, w0, w1, w2, w3);
+                    const uint32_t w1x = (i & 3) == 0 ? w0 : (i & 3) == 1 ? w1 : (i & 3) == 2 ? w2 : w3;
+                    w1 = w1x;
                     uint32_t comp = (pk >> kCompShift) & 7u;
                     uint32_t age = pk & kAgeMask;
                     // _calculate_lap_time :313-332

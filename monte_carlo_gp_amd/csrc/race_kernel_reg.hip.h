@@ -21,7 +21,7 @@
 //     W    [8][B]  u32   draw words of the overtake attempts of one pass (8 at a time)
 // with row stride = the block size B (bank = f(lane) only: conflict-free gathers by driver index), plus the
 // block-shared tables: inverse-normal cubic, per-driver {variance, base pace}, {base pace, degradation} x 2^31,
-// per-(compound, driver) {degradation x factor, pit threshold, DNF threshold}, per-compound pace delta, the pit rule, the
+// per-(compound, driver) {degradation x factor, pit threshold}, per-compound pace delta, the pit rule, the
 // n x n histogram (u32) and the transposed grid matrix.
 //
 // Random draws of a lap are addressed by the car's PLACE in the field order (its register index): the block of
@@ -132,6 +132,9 @@ __host__ __device__ constexpr int reg_block_waves(int n)
     return waves;
 }
 
+// device memory the kernel wants for the lanes' retirement lists: (n + 1) words per lane of the launch
+__host__ __device__ constexpr size_t reg_retire_ws_bytes(int n, size_t lanes) { return (size_t)(n + 1) * lanes * 4; }
+
 template <int N>
 struct RegGeo {
     static constexpr int kWaves = reg_block_waves(N);
@@ -223,6 +226,25 @@ template <int N, size_t... G>
 __device__ __forceinline__ void network_sort_impl(double (&cum)[N], uint32_t (&pk)[N], std::index_sequence<G...>)
 {
     (network_group<N, (int)G>(cum, pk), ...);
+}
+
+// The same network on plain integer keys (classification): a comparator is one v_min_u32 and one v_max_u32.
+template <int N, size_t... C>
+__device__ __forceinline__ void network_sort_keys_impl(uint32_t (&key)[N], std::index_sequence<C...>)
+{
+    constexpr MergeExchange<N> net{};
+    auto cx = [&](int a, int b) {
+        const uint32_t lo = key[a] < key[b] ? key[a] : key[b], hi = key[a] < key[b] ? key[b] : key[a];
+        key[a] = lo;
+        key[b] = hi;
+    };
+    (cx(net.a[C], net.b[C]), ...);
+}
+template <int N>
+__device__ __forceinline__ void network_sort_keys(uint32_t (&key)[N])
+{
+    constexpr MergeExchange<N> net{};
+    network_sort_keys_impl<N>(key, std::make_index_sequence<(size_t)net.n>{});
 }
 
 // Forward bubble pass from slot I: comparators (I, I+1), (I+1, I+2), .. (N-2, N-1), four to an instruction block.
@@ -442,12 +464,14 @@ __host__ __device__ inline double reg_time_floor(const KParams &kp)
     return floor_;
 }
 
-// The register kernel keeps the per-lap DNF threshold in 32 bits: a driver who retires with CERTAINTY on every lap
-// (probability >= 1, threshold 2^32) does not fit and sends the whole problem to the generic kernel.
+// Problems the register kernel takes (everything else runs on the generic kernel, with the same results).  Retirement
+// probabilities need no condition: the retirement lap of every driver is drawn once per race (draw_retirement_lap,
+// race_common.hip.h), where a probability >= 1 is just a survival threshold of 0.
 __host__ __device__ inline bool reg_kernel_serves(const KParams &kp)
 {
-    for (int d = 0; d < kp.n; ++d)
-        if (kp.t_dnf[d] > 0xFFFFFFFFull) return false;
+    // an overtake attempt is told from its threshold being non-zero, which wants overtake_delta >= 0 (dl > delta >= 0
+    // makes ceil(dl 2^31) >= 1); a negative delta -- attempts at a pace DEFICIT -- is the generic kernel's
+    if (!(kp.overtake_delta >= 0.0)) return false;
     // The kernel's tables carry powers of two (pace x 2^31, degradation x 2^-16 or x 2^15): exact, a power of two
     // commutes with every rounding, unless the scaled value leaves the normal range.  Magnitudes no race has, but the
     // kernel is bit-exact on what it accepts: anything near the ends of binary64 goes to the generic kernel.
@@ -501,8 +525,7 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         *reinterpret_cast<double *>(r) = (P->comp_deg[c] * P->factor[d]) * kAgeFieldUnit;
         // pit word: threshold << 16, to be compared with (tyre age + 1) << 16 taken straight from pk (:454-465)
         *reinterpret_cast<uint32_t *>(r + 8) = (uint32_t)P->opt_laps[d * kCompStride + c] << 16;
-        // DNF draw threshold, 32 bits: ceil(p 2^32) for p < 1 (reg_kernel_serves() keeps p >= 1 away from this kernel)
-        *reinterpret_cast<uint32_t *>(r + 12) = (uint32_t)P->t_dnf[d];                              // reference :190-194
+        *reinterpret_cast<uint32_t *>(r + 12) = 0u;
     }
     for (uint32_t i = tid; i < 32u; i += B)
         *reinterpret_cast<uint32_t *>(smem + G::oLut + i * 4) =
@@ -542,11 +565,12 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                              uint32_t *__restrict__ ticket, uint64_t n_sims,
                                              uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
                                              uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid,
-                                             uint32_t n_chunks)
+                                             uint32_t n_chunks, uint32_t *__restrict__ retire_ws_base, uint32_t ws_stride,
+                                             uint32_t ws_first_lane)
 {
     using G = RegGeo<N>;
     constexpr int B = G::B;
-    static_assert(MCGP_STEP_BATCH % 2 == 0, "a Philox block serves two consecutive places");
+    static_assert(MCGP_STEP_BATCH % 4 == 0, "a Philox block serves four consecutive places");
     const uint32_t tid4 = tid * 4u, tid8 = tid * 8u;
     const int L = P->total_laps;
     const int track = P->track;
@@ -570,7 +594,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     // Everything the lap step of one slot reads from LDS.
     struct SlotIn {
         uint32_t pitw;          // pit threshold << 16
-        uint32_t tdnf;          // DNF draw threshold (32 bits)
         double last, var, base, eff, cdelta, drs;
         uint32_t la;            // byte offset of the driver's LAST row
         uint32_t fit;           // compound and used-set a pit stop on this lap would leave, positioned as in pk
@@ -585,7 +608,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);
         r.var = vb.x;
         r.base = vb.y;
-        lds_ld_f64_u32x2(G::oIc + ic, r.eff, r.pitw, r.tdnf);
+        uint32_t pad;
+        lds_ld_f64_u32x2(G::oIc + ic, r.eff, r.pitw, pad);
         r.cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));                 // 16 x compound
         r.drs = lds_ld<double>(G::oDrs + (p & k3Drs));                            // 0.0 or drs_delta
         return r;
@@ -759,6 +783,86 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         for (int d = 0; d < N; ++d) lds_st<double>(l_row(d), 0.0);          // last_lap_time is not set on lap 1 (Q3)
         network_sort<N>(cum, pk);
         update_positions_reg<N>(cum, pk, false, dirty_thr);
+
+        // ================= retirements of laps 2..L, reference :190-197, drawn once per race =================
+        // The reference draws one uniform per running car per lap and retires the car if it is below the driver's per-lap
+        // probability p: the lap of the first success is geometric, independent of everything else in the race.  It is
+        // drawn HERE, from one word per driver (draw_retirement_lap, race_common.hip.h), which halves the Philox blocks
+        // of the lap step (a block then serves four cars' lap noise instead of two cars' noise + retirement draws).
+        // The survival thresholds S_k are wave-uniform (scalar unit: one s_mul_hi per lap); a lane counts the laps its
+        // word survives.  A lane's retirements go to its column of `retire_ws` (device memory: about one entry per
+        // race, read back only on the lap of a retirement) as keys lap << 5 | driver; the smallest is kept in `next_out`.
+        // `next_out` holds the lane's next two retirements, 15-bit keys (lap << 5 | driver, 0x7FFF = none) in bits 0..14
+        // and 16..30, bit 31 = "the list in device memory has more": the race loop tests one register per lap and goes to
+        // memory only for a lane's third, fifth .. retirement.
+        constexpr uint32_t kNoKey = 0x7FFFu;
+        // the two smallest keys above `after` of this lane's list in device memory, packed as above
+        auto retirements_after = [&](const uint32_t *ws, uint32_t after) -> uint32_t {
+            const uint32_t n_out = ws[(size_t)N * ws_stride];
+            uint32_t k1 = kNoKey, k2 = kNoKey, left = 0u;
+#pragma unroll 1
+            for (uint32_t k = 0; k < n_out; ++k) {
+                const uint32_t e = ws[(size_t)k * ws_stride];
+                if (e > after) {
+                    ++left;
+                    const uint32_t hi = e > k1 ? e : k1;
+                    k1 = e < k1 ? e : k1;
+                    k2 = hi < k2 ? hi : k2;
+                }
+            }
+            return k1 | (k2 << 16) | (left > 2u ? 0x80000000u : 0u);
+        };
+        uint32_t next_out;
+        {
+            // (this lane's column of the workspace: formed where it is used, from a thread index the optimiser cannot trace
+            //  back, so that no 64-bit address sits in registers for the whole race)
+            uint32_t tid_w = tid;
+            pin(tid_w);
+            uint32_t *retire_ws = retire_ws_base + ws_first_lane + tid_w;
+            uint32_t n_out = 0u, k1 = kNoKey, k2 = kNoKey;
+            // four drivers at a time (the four words of one Philox block): their survival thresholds advance together on
+            // the scalar unit, one loop iteration per lap for the four of them
+#pragma unroll 1
+            for (int d0 = 0; d0 < N; d0 += 4) {
+                uint32_t rw[4];
+                philox4x32_10(c0, c1, 0u, kPurposeRetire | (uint32_t)(d0 >> 2), seed_lo, seed_hi, rw[0], rw[1], rw[2], rw[3]);
+                uint32_t q[4], S[4], survived[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t t = d0 + j < N ? P->t_dnf[d0 + j] : 0ull;         // ceil(p 2^32), 0 .. 2^32
+                    // p = 0 (t = 0) never retires: a threshold no word reaches ... q = 2^32 does not fit, so such a
+                    // driver is skipped below; p >= 1 (t = 2^32) has q = 0 and retires on lap 2
+                    q[j] = (uint32_t)(4294967296ull - t);
+                    S[j] = q[j];
+                    survived[j] = 0u;
+                }
+#pragma unroll 1
+                for (int k = (MCGP_SKIP & 256) ? L + 1 : 2; k <= L; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        survived[j] += rw[j] < S[j] ? 1u : 0u;                       // survives lap k
+                        S[j] = retire_next_threshold(S[j], q[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = d0 + j;
+                    if (d >= N) continue;
+                    if (P->t_dnf[d] == 0ull) continue;                               // (wave-uniform)
+                    const uint32_t out_lap = 2u + survived[j];
+                    if (out_lap <= (uint32_t)L && !(MCGP_SKIP & 256)) {
+                        const uint32_t key = (out_lap << 5) | (uint32_t)d;
+                        retire_ws[(size_t)n_out * ws_stride] = key;
+                        ++n_out;
+                        const uint32_t hi = key > k1 ? key : k1;
+                        k1 = key < k1 ? key : k1;
+                        k2 = hi < k2 ? hi : k2;
+                    }
+                }
+            }
+            retire_ws[(size_t)N * ws_stride] = n_out;
+            next_out = k1 | (k2 << 16) | (n_out > 2u ? 0x80000000u : 0u);
+        }
 
         // ================= laps 2..L, reference :166-228 =================
         int drs_disabled_until = 0;
@@ -964,12 +1068,30 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #endif
             }
 
+            // ---- this lap's retirements (:194-197): the driver whose drawn lap this is gets the SIGN of his LAST row set --
+            // the lap step reads that row anyway (the car ahead's last lap, :179-183) and takes the sign for "retires now";
+            // lap times are positive (reg_time_floor), a row is rewritten by every lap its driver runs and never read once
+            // he is out.  Rare per lane (a retirement per race), so the wave branches; the next key comes from the lane's
+            // list in device memory.
+            while (!(MCGP_SKIP & 512) && MCGP_ANY(((next_out >> 5) & 0x3FFu) == (uint32_t)lap)) {
+                if (((next_out >> 5) & 0x3FFu) == (uint32_t)lap) {
+                    const uint32_t key = next_out & kNoKey;
+                    lds_or_u32(G::oLast + (key & 31u) * (uint32_t)(B * 8) + tid8 + 4u, 0x80000000u);   // (no value comes back: nothing to wait for)
+                    next_out = (next_out & 0x80000000u) | (kNoKey << 16) | ((next_out >> 16) & kNoKey);
+                    if (next_out == (0x80000000u | (kNoKey << 16) | kNoKey)) {      // both used, more in memory
+                        uint32_t tid_w = tid;
+                        pin(tid_w);
+                        next_out = retirements_after(retire_ws_base + ws_first_lane + tid_w, key);
+                    }
+                }
+            }
+
             // ---- every running car's lap (:179-223) with its pit stop (:433-494), in time-rank order ----
             // Written without branches: every slot computes its lap and the results are merged by selects, so the
             // LDS gathers of MCGP_STEP_BATCH slots stay in flight together (nothing can be sunk into a branch) and
             // the wave does not pay exec-mask bookkeeping per car.  What a retired car "computes" is discarded:
             // +0.0 on its time, its pk kept, and a LAST value nobody reads (only running cars feed `carry`).
-            // The draws of places 2j and 2j+1 are the four words of ONE Philox block, computed here between the
+            // The lap-noise draws of places 4j .. 4j+3 are the four words of ONE Philox block, computed here between the
             // gathers and their use (it covers their latency) and consumed from registers.
             {
                 double fuel = 110.0 - 1.5 * (double)(lap - 1);
@@ -986,31 +1108,29 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j)
                         if (i0 + j < N) in[j] = load_slot(pk[i0 + j], lut_base);
-                    uint32_t w[MCGP_STEP_BATCH / 2][4];
+                    uint32_t w[MCGP_STEP_BATCH / 4][4];
 #pragma unroll
-                    for (int b = 0; b < MCGP_STEP_BATCH / 2; ++b) {
+                    for (int b = 0; b < MCGP_STEP_BATCH / 4; ++b) {
                         w[b][0] = w[b][1] = w[b][2] = w[b][3] = 0u;
-                        if (i0 + 2 * b < N && !((MCGP_SKIP & 128) && b > 0))
-                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | (uint32_t)((i0 >> 1) + b), k0l, k1l,
+                        if (i0 + 4 * b < N)
+                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | (uint32_t)((i0 >> 2) + b), k0l, k1l,
                                           w[b][0], w[b][1], w[b][2], w[b][3]);
                     }
                     float z[MCGP_STEP_BATCH];
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j)
-                        z[j] = (i0 + j < N) ? normal_from_u32_rows((MCGP_SKIP & 128) ? w[0][j & 3] : w[j >> 1][2 * (j & 1) + 1], norm_row) : 0.0f;
+                        z[j] = (i0 + j < N) ? normal_from_u32_rows(w[j >> 2][j & 3], norm_row) : 0.0f;
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
                         const int i = i0 + j;
                         if (i >= N) continue;
                         const SlotIn &s = in[j];
                         const uint32_t p = pk[i];
-                        const uint32_t wd = w[j >> 1][2 * (j & 1)];
                         const bool active = !(p & k3Dnf);                   // running at the start of the lap
-                        // this lap's DNF draw (:194-197): u < p  <=>  word < ceil(p 2^32)  (p < 1 here: a field with a
-                        // driver who retires with certainty every lap is served by the generic kernel, see mcgp_hip.hip)
-                        const bool dnf_hit = (MCGP_SKIP & 128) ? false : wd < s.tdnf;
+                        // retires on this lap (:194-197): the sign of the driver's LAST row, set above
+                        const bool dnf_hit = __double2hiint(s.last) < 0;
                         const bool run = active && !dnf_hit;
-                        const double ahead_last = carry;                    // last lap of the running car ahead  :179-183
+                        const double ahead_last = carry;                    // last lap of the running car ahead  :179-183 (sign: see above)
                         carry = active ? s.last : carry;
                         const uint32_t agef = p & k3AgeMask;
                         const double tire = (double)agef * s.eff;                                   // :319-322 (eff x 2^-16)
@@ -1018,8 +1138,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const double noise = 0.0 + s.var * (double)z[j];                            // :330
                         const double clean = s.base + tire - fuel_effect + s.cdelta - drs_gain + noise;   // :332
                         const double dirty_time = clean + dirty_pen;                                // :213
-                        const double held = max_f64(ahead_last, dirty_time);                        // :215 (neither is NaN)
-                        const bool in_dirty = (p & k3Dirty) && ahead_last > 0;                      // :209-212
+                        const double held = max_abs_f64(ahead_last, dirty_time);                    // :215 (neither is NaN)
+                        const bool in_dirty = (p & k3Dirty) && fabs(ahead_last) > 0;                // :209-212
                         const double lap_time = in_dirty ? held : clean;
                         // pit stop (:450-492): (tyre age + 1) << 16 against the pit word; compound and used-set from
                         // the rule table (pit_rule_word)
@@ -1053,8 +1173,26 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // succeed.  Everything is scaled by 2^31 (tables, reg_load_tables): u < min(0.5, delta / 2) for the
                 // uniform u = w 2^-32 is  w < 2^31  and  w < delta 2^31,  i.e.  w < thr = min(ceil(delta 2^31), 2^31)
                 // -- one integer per pair instead of a binary64 delta kept across the draw-word generation.
+                // ---- overtakes: draw words ----
+                // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4.  The first eight -- all that
+                // all but a few wave-passes in a thousand need -- are drawn FIRST, into the eight rows of the W plane: the
+                // stage below then fetches a pair's word the moment its row is known, and no array of addresses or of
+                // candidate bits has to live across the Philox blocks (which cost a dozen registers themselves).
+                {
+                    uint32_t o0, o1, o2, o3;
+                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass), k0l, k1l, o0, o1, o2, o3);
+                    lds_st<uint32_t>(w_row(0), o0);
+                    lds_st<uint32_t>(w_row(1), o1);
+                    lds_st<uint32_t>(w_row(2), o2);
+                    lds_st<uint32_t>(w_row(3), o3);
+                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 1), k0l, k1l, o0, o1, o2, o3);
+                    lds_st<uint32_t>(w_row(4), o0);
+                    lds_st<uint32_t>(w_row(5), o1);
+                    lds_st<uint32_t>(w_row(6), o2);
+                    lds_st<uint32_t>(w_row(7), o3);
+                }
                 uint32_t thr[N];
-                uint32_t ow[N];                  // first the W-plane address of the pair's draw word, then the word
+                uint32_t ow[N];                  // ow[i] = the draw word of the attempt at pair i
                 // W-plane address of the NEXT attempt's word: a running sum over the candidates so far (row k of the plane
                 // holds the word of the lane's k-th attempt), advanced inside ovt_threshold by the compare that makes
                 // the pair a candidate
@@ -1088,7 +1226,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                     // candidate iff dl > overtake_delta (:522); threshold min(ceil(dl), 2^31) (:523-524)
                                     uint32_t next;
                                     ovt_threshold(dl, od31, row, row_stride, thr[i], next);
-                                    ow[i] = row;
+                                    // (a pair that is no candidate fetches the word of the next attempt, or one just past
+                                    //  the plane: its threshold is 0)
+                                    ow[i] = lds_ld<uint32_t>(G::oW + row);
                                     row = next;
                                 }
                                 pace_prev = pace;
@@ -1101,16 +1241,13 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const uint32_t words_end = row - tid4;          // = attempts of this lane x the row stride
                 MCGP_STAT(0 + pass, words_end != 0u);
                 if (words_end == 0u) break;
-                // ---- overtakes: draw words ----
-                // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4.  Up to 8 attempts per lane
-                // -- all but a few wave-passes in a thousand -- go through the W plane in one go: ow[i] = the word of the
-                // attempt at pair i.  A wave with a busier lane takes the general path, 8 attempts at a time, and leaves
-                // its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
+                // A wave with a lane that has more than eight attempts takes the general path, 8 attempts at a time, and
+                // leaves its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
                 if (__builtin_expect(MCGP_ANY(words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
-                    // the candidate mask, from the addresses: a candidate advanced the running row
+                    // the candidate mask: a candidate's threshold is at least 1 (dl > overtake_delta >= 0, reg_kernel_serves)
                     uint32_t cand = 0u;
 #pragma unroll
-                    for (int i = 1; i < N; ++i) cand |= ((i + 1 < N ? ow[i + 1] : row) != ow[i]) ? (1u << i) : 0u;
+                    for (int i = 1; i < N; ++i) cand |= thr[i] != 0u ? (1u << i) : 0u;
                     uint32_t hits = 0u, rest = cand;
 #pragma unroll 1
                     for (int chunk = 0; rest != 0u; ++chunk) {
@@ -1121,7 +1258,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll 1
                         for (int b = 0; b < 2; ++b) {
                             uint32_t o0, o1, o2, o3;
-                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 2 * chunk + b), k0l, k1l, o0, o1, o2, o3);
+                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 2 * chunk + b), k0l,
+                                          k1l, o0, o1, o2, o3);
                             lds_st<uint32_t>(w_row(4 * b + 0), o0);
                             lds_st<uint32_t>(w_row(4 * b + 1), o1);
                             lds_st<uint32_t>(w_row(4 * b + 2), o2);
@@ -1142,24 +1280,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         thr[i] = (hits >> i) & 1u;
                         ow[i] = 0u;
                     }
-                } else {
-                    uint32_t o0, o1, o2, o3;
-                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass), k0l, k1l, o0, o1, o2, o3);
-                    lds_st<uint32_t>(w_row(0), o0);
-                    lds_st<uint32_t>(w_row(1), o1);
-                    lds_st<uint32_t>(w_row(2), o2);
-                    lds_st<uint32_t>(w_row(3), o3);
-                    if (words_end > (uint32_t)(4 * B * 4)) {
-                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 1), k0l, k1l, o0, o1, o2, o3);
-                        lds_st<uint32_t>(w_row(4), o0);
-                        lds_st<uint32_t>(w_row(5), o1);
-                        lds_st<uint32_t>(w_row(6), o2);
-                        lds_st<uint32_t>(w_row(7), o3);
-                    }
-                    // (a pair that is no candidate reads the word of the next attempt, or just past the plane: its
-                    //  threshold is 0)
-#pragma unroll
-                    for (int i = 1; i < N; ++i) ow[i] = lds_ld<uint32_t>(G::oW + ow[i]);
                 }
                 // ---- overtakes: success test and write-back chain ----
                 // :523-531 in sorted order, each pair seeing the previous pair's mutation (Q15).  Branch-free: the
@@ -1193,6 +1313,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         //     1 << 26 | (2047 - lap) << 15 | (31 - g) << 10 | grid slot << 5,     g = index of its time among the
         // distinct times in ascending order (equal times share g and fall back to grid order, the reference's
         // stable tie; lap-1 retirements carry distinct negative times, see lap 1).  The driver rides in the low 5 bits.
+        // The keys are sorted in registers by the lap loop's network (a comparator on integers is a v_min_u32 and a
+        // v_max_u32); the insertion sort in LDS that used to stand here ran a data-dependent loop per car, as long as the
+        // wave's slowest lane needed -- every retirement of a wave's 64 races stretched it for all of them.
+        uint32_t key[N];
         {
             uint32_t g = 0u;
 #pragma unroll
@@ -1203,40 +1327,26 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const uint32_t lapf = (p >> k3AgeShift) & 0x7FFu;
                 const uint32_t key_dnf = (1u << 26) | ((2047u - lapf) << 15) | ((31u - g) << 10) | ((p >> k3GposShift) << 5) | id;
                 const uint32_t key_run = ((uint32_t)i << 5) | id;
-                lds_st<uint32_t>(l_row(i), (p & k3Dnf) ? key_dnf : key_run);
+                key[i] = (p & k3Dnf) ? key_dnf : key_run;
             }
         }
-#pragma unroll 1
-        for (int i = 1; i < N; ++i) {                                   // insertion sort of the keys (LAST rows, dead now)
-            const uint32_t kx = lds_ld<uint32_t>(l_row(i));
-            int j = i;
-            while (j > 0) {
-                const uint32_t ky = lds_ld<uint32_t>(l_row(j - 1));
-                if (!(ky > kx)) break;
-                lds_st<uint32_t>(l_row(j), ky);
-                --j;
-            }
-            lds_st<uint32_t>(l_row(j), kx);
-        }
+        network_sort_keys<N>(key);
         // finishing order: N bytes per simulation, contiguous per lane.  Four positions are packed into one dword
         // store when the lane's N-byte record is dword aligned (N % 4 == 0 and an aligned buffer): N / 4 stores per
         // lane that the L2 merges into full lines, instead of N single-byte stores.
-        const bool dword_orders = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(orders) & 3u) == 0);
-        uint32_t packed = 0u;
-#pragma unroll 1
-        for (int p = 0; p < N; ++p) {
-            const uint32_t d = lds_ld<uint32_t>(l_row(p)) & 31u;
-            if (!live) break;
-            atomicAdd(&s_hist[d * N + p], 1u);                       // reference :93-94
+        if (live) {
+#pragma unroll
+            for (int p = 0; p < N; ++p) atomicAdd(&s_hist[(key[p] & 31u) * N + p], 1u);              // reference :93-94
             if (orders) {
+                const bool dword_orders = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(orders) & 3u) == 0);
                 if (dword_orders) {
-                    packed |= d << (8 * (p & 3));
-                    if ((p & 3) == 3) {
-                        *reinterpret_cast<uint32_t *>(orders + local * (uint64_t)N + (uint64_t)(p - 3)) = packed;
-                        packed = 0u;
-                    }
+#pragma unroll
+                    for (int p = 0; p + 3 < N; p += 4)
+                        *reinterpret_cast<uint32_t *>(orders + local * (uint64_t)N + (uint64_t)p) =
+                            (key[p] & 31u) | ((key[p + 1] & 31u) << 8) | ((key[p + 2] & 31u) << 16) | ((key[p + 3] & 31u) << 24);
                 } else {
-                    orders[local * (uint64_t)N + (uint64_t)p] = (uint8_t)d;
+#pragma unroll
+                    for (int p = 0; p < N; ++p) orders[local * (uint64_t)N + (uint64_t)p] = (uint8_t)(key[p] & 31u);
                 }
             }
         }
@@ -1248,7 +1358,7 @@ __global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                 uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,
-                uint32_t *__restrict__ ticket)
+                uint32_t *__restrict__ ticket, uint32_t *__restrict__ retire_ws)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // host and kernel must agree on the geometry, and the rows are addressed by absolute LDS address
@@ -1256,7 +1366,9 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) __builtin_trap();
     reg_load_tables<N>(P, smem, threadIdx.x);
     __syncthreads();
-    reg_simulate<N>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks);
+    // retirement lists: one column per lane of the launch, N + 1 rows (reg_retire_ws_bytes)
+    reg_simulate<N>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
+                    retire_ws, (uint32_t)(gridDim.x * RegGeo<N>::B), (uint32_t)(blockIdx.x * RegGeo<N>::B));
     __syncthreads();
     reg_flush_hist<N>(smem, threadIdx.x, hist);
 }

@@ -266,8 +266,14 @@ double orc_phi_inverse_tail(uint64_t q53, float z_start) { return phi_inverse_ta
 /*   GRID  (lap 0)  index = slot >> 2, word = slot & 3                         */
 /*   EVENT (lap)    words: red flag, safety car, VSC, VSC tyre draw            */
 /*   CAR   (lap 1)  index = driver; words: DNF, lap noise, start delta          */
-/*   CAR   (lap>=2) index = place >> 1 (one block serves two cars), words       */
-/*                   2 (place & 1) + {0: DNF, 1: lap noise}, where `place` is   */
+/*   RETIRE (lap 0) index = driver >> 2, word driver & 3: the lap (>= 2) on     */
+/*                   which the driver retires, drawn ONCE per race: with        */
+/*                   t = ceil(p 2^32), q = 2^32 - t the car survives lap k iff  */
+/*                   w < S_k, S_2 = q, S_{k+1} = floor(S_k q / 2^32) (the lap   */
+/*                   of the first success of the reference's per-lap draw,      */
+/*                   :190-197, is geometric; philox_retirement_lap below)       */
+/*   CAR   (lap>=2) index = place >> 2 (one block serves four cars), word       */
+/*                   place & 3 = lap noise, where `place` is                    */
 /*                   the car's place in the FIELD ORDER the lap starts with:    */
 /*                   all cars, retired ones included, in the time order of the  */
 /*                   end of the previous lap (stable, i.e. grid order on equal  */
@@ -276,7 +282,7 @@ double orc_phi_inverse_tail(uint64_t q53, float z_start) { return phi_inverse_ta
 /*   OVT   (lap)    the k-th overtake ATTEMPT of pass p (k counted along the   */
 /*                   pass's sorted order) reads word k & 3 of index 8p + k / 4  */
 /* ------------------------------------------------------------------------- */
-enum { PURPOSE_GRID = 0, PURPOSE_EVENT = 1, PURPOSE_CAR = 2, PURPOSE_OVT = 3 };
+enum { PURPOSE_GRID = 0, PURPOSE_EVENT = 1, PURPOSE_CAR = 2, PURPOSE_OVT = 3, PURPOSE_RETIRE = 4 };
 
 typedef struct {
     int mode;
@@ -330,12 +336,44 @@ static double draw_event(rng_t *r, int lap, int which)
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :168,171,174,392 */
     return philox_uniform(r, (uint32_t)lap, PURPOSE_EVENT, 0, which);
 }
-/* `who`: the driver index on lap 1, the car's place in the field order from lap 2 on (see above) */
+/* `who`: the driver index (lap 1 of the counter-based back-ends; the MT back-end draws in sequence, every lap) */
 static double draw_dnf(rng_t *r, int lap, int who)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return mt_res53(&r->mt->py);          /* :194,287 */
-    if (lap == 1) return philox_uniform(r, 1u, PURPOSE_CAR, (uint32_t)who, 0);
-    return philox_uniform(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)who >> 1, 2 * (who & 1));
+    (void)lap;
+    return philox_uniform(r, 1u, PURPOSE_CAR, (uint32_t)who, 0);
+}
+/* Counter-based back-ends, laps >= 2: the lap on which `driver` retires, 0 = not within `total_laps` (see the table
+ * above).  The reference draws u < p afresh every lap (:190-197); the lap of the first success is geometric and is
+ * drawn here from one word.  PHILOX: 32-bit word against 32-bit thresholds, exactly what the HIP kernels compute
+ * (csrc/race_common.hip.h: draw_retirement_lap).  PHILOX53: the same word refined to 53 bits (left-aligned in 64)
+ * against 64-bit thresholds S_2 = q, S_{k+1} = floor(S_k q / 2^64), q = 2^64 - ceil(p 2^64). */
+static int philox_retirement_lap(const rng_t *r, int driver, double p, int total_laps)
+{
+    const uint32_t w = philox_word(r, 0u, PURPOSE_RETIRE, (uint32_t)driver >> 2, driver & 3);
+    if (!(p > 0.0)) return 0;                                              /* also NaN: `u < nan` is false */
+    if (r->mode != MCGP_ORACLE_RNG_PHILOX53) {
+        const double x = p * 4294967296.0;                                 /* exact */
+        const uint64_t t = x >= 4294967296.0 ? 4294967296ull : (uint64_t)ceil(x);
+        const uint32_t q = (uint32_t)(4294967296ull - t);
+        uint32_t S = q;
+        for (int k = 2; k <= total_laps; k++) {
+            if (!(w < S)) return k;
+            S = (uint32_t)(((uint64_t)S * (uint64_t)q) >> 32);
+        }
+        return 0;
+    }
+    const uint64_t Q = ((uint64_t)w << 32) | ((uint64_t)philox_extra21(r, 0u, PURPOSE_RETIRE, (uint32_t)driver >> 2, driver & 3) << 11);
+    if (p >= 1.0) return total_laps >= 2 ? 2 : 0;
+    const double x = p * 18446744073709551616.0;                           /* exact: p 2^64 < 2^64 */
+    const uint64_t t = (uint64_t)ceil(x);                                  /* >= 1 */
+    const uint64_t q = (uint64_t)0 - t;                                    /* 2^64 - t */
+    uint64_t S = q;
+    for (int k = 2; k <= total_laps; k++) {
+        if (!(Q < S)) return k;
+        S = (uint64_t)(((unsigned __int128)S * (unsigned __int128)q) >> 64);
+    }
+    return 0;
 }
 static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
 {
@@ -347,7 +385,7 @@ static double draw_lap_noise(rng_t *r, int lap, int who, double scale)
 {
     if (r->mode == MCGP_ORACLE_RNG_MT) return orc_mt_np_normal(r->mt, 0.0, scale);   /* :330 */
     const double z = lap == 1 ? philox_normal(r, 1u, PURPOSE_CAR, (uint32_t)who, 1)
-                              : philox_normal(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)who >> 1, 2 * (who & 1) + 1);
+                              : philox_normal(r, (uint32_t)lap, PURPOSE_CAR, (uint32_t)who >> 2, who & 3);
     return 0.0 + scale * z;
 }
 static double draw_start_delta(rng_t *r, int driver, double scale)
@@ -709,6 +747,10 @@ static void simulate_race(const sim_t *s, const uint8_t *grid, uint8_t *order_ou
     int drs_disabled_until = 0;
     int place[MCGP_ORACLE_MAX_CARS];                    /* field order (Philox draw addresses only) */
     field_order_sort(cars, n, place);
+    int out_lap[MCGP_ORACLE_MAX_CARS];                  /* by DRIVER: lap of retirement (counter-based back-ends only) */
+    const int counter_based = s->rng->mode != MCGP_ORACLE_RNG_MT;
+    if (counter_based)
+        for (int d = 0; d < n; d++) out_lap[d] = philox_retirement_lap(s->rng, d, s->drv->lap_dnf[d], cfg->total_laps);
 
     for (int lap = 2; lap <= cfg->total_laps; lap++) {
         /* :168-176, short-circuit chain (Q8) */
@@ -735,7 +777,9 @@ static void simulate_race(const sim_t *s, const uint8_t *grid, uint8_t *order_ou
         for (int i = 0; i < n; i++) {
             car_t *car = &cars[i];
             if (car->dnf) continue;
-            if (draw_dnf(s->rng, lap, place[i]) < s->drv->lap_dnf[car->driver]) {
+            /* :194-197.  MT: the reference's draw.  Counter-based: the lap drawn for this driver before the race. */
+            if (counter_based ? out_lap[car->driver] == lap
+                              : draw_dnf(s->rng, lap, place[i]) < s->drv->lap_dnf[car->driver]) {
                 car->dnf = 1;
                 car->lap = lap;
                 continue;

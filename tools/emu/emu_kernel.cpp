@@ -67,9 +67,10 @@ static int run_size(const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offse
         constexpr uint32_t B = mcgp::RegGeo<N>::B;
         const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
         for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N>(&kp, mcgp::smem, t);
+        std::vector<uint32_t> retire_ws((size_t)(N + 1) * B);        // the lanes' retirement lists (device memory on the GPU)
         for (uint32_t t = 0; t < B; ++t)
             mcgp::reg_simulate<N>(&kp, mcgp::smem, t, nullptr, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32),
-                                  orders, fixed_grid, n_chunks);
+                                  orders, fixed_grid, n_chunks, retire_ws.data(), B, 0u);
         for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N>(mcgp::smem, t, hist);
         return 0;
     } else {
@@ -105,7 +106,7 @@ extern "C" int emu_run(const mcgp_config *cfg, const mcgp_drivers *drv, const do
     *err = none;
     const int rc = mcgp::build_params(cfg, drv, grid_probs, n, &kp, err);
     if (rc != MCGP_OK) return rc;
-    if (!mcgp::reg_kernel_serves(kp)) { *err = "served by the generic kernel (a DNF probability >= 1)"; return -100; }
+    if (!mcgp::reg_kernel_serves(kp)) { *err = "served by the generic kernel (reg_kernel_serves)"; return -100; }
     threadIdx = {0, 0, 0};
     blockIdx = {0, 0, 0};
     blockDim = {1, 1, 1};

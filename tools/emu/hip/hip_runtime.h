@@ -32,6 +32,12 @@ inline void __syncthreads() {}
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+inline int __double2hiint(double x)
+{
+    uint64_t u;
+    std::memcpy(&u, &x, 8);
+    return (int)(uint32_t)(u >> 32);
+}
 inline float __uint_as_float(uint32_t u)
 {
     float f;

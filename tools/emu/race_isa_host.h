@@ -9,6 +9,7 @@ inline void minmax_f64(double a, double b, double &lo, double &hi)
     hi = a < b ? b : a;
 }
 inline double max_f64(double a, double b) { return a < b ? b : a; }
+inline double max_abs_f64(double a, double b) { return std::fabs(a) < b ? b : std::fabs(a); }
 inline void cmpx_time(double &ca, uint32_t &pa, double &cb, uint32_t &pb)
 {
     if (ca > cb) {
@@ -71,6 +72,7 @@ inline void lds_st(uint32_t addr, T v)
 {
     std::memcpy(smem + addr, &v, sizeof(T));
 }
+inline void lds_or_u32(uint32_t addr, uint32_t bits) { lds_st<uint32_t>(addr, lds_ld<uint32_t>(addr) | bits); }
 struct f64x2 {
     double x, y;
 };
