@@ -125,6 +125,18 @@ int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const d
                         uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
                         int32_t device, void *stream, uint64_t *d_hist, uint8_t *d_orders);
 
+/* Several problems in ONE launch: the reference predicts a race from 10 000 simulations (reference
+ * src/predictor.py:284) and a backtest runs the races of a season one after the other (src/validation.py:179-185); at
+ * that size a launch lasts as long as one race of one lane and most of the device idles.  n_problems races of the same
+ * field size n, n_sims simulations each: cfgs[p], drvs[p], grid_probs[p] (n x n) as for mcgp_run, simulation ids
+ * sim_offsets[p] .. sim_offsets[p] + n_sims - 1 (NULL: 0) under seeds[p]; hist_out = [n_problems][n][n], ACCUMULATED
+ * into.  Every problem's histogram is bit-identical to what mcgp_run gives for it alone.  Host buffers in and out,
+ * blocking.  MCGP_E_BAD_ARG also for a problem outside the register kernel's domain (lap times near zero: mcgp_run
+ * serves those on its second kernel). */
+int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_drivers *drvs,
+                       const double *const *grid_probs, uint32_t n, uint64_t n_sims, const uint64_t *sim_offsets,
+                       const uint64_t *seeds, int32_t device, uint64_t *hist_out);
+
 /* simulate_race (reference :147-242): one race from a FIXED starting grid
  * (grid[p] = driver index on slot p), simulation id sim_id.  order_out[p] = driver
  * index classified p-th.  Bit-identical to what mcgp_run computes for a simulation

@@ -167,7 +167,7 @@ def assert_single_hip_runtime():
 
 _lib = None
 
-EXPORTS = ('mcgp_abi_version', 'mcgp_build_hash', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
+EXPORTS = ('mcgp_abi_version', 'mcgp_build_hash', 'mcgp_run_batch', 'mcgp_device_count', 'mcgp_last_error', 'mcgp_run', 'mcgp_run_device',
            'mcgp_simulate_race', 'mcgp_grid_probs', 'mcgp_run_from_ratings', 'mcgp_last_kernel_ms',
            'mcgp_stream_kernel_ms', 'mcgp_elo_season',
            'mcgp_last_launch_info', 'mcgp_last_kernel_name')
@@ -199,6 +199,11 @@ def lib():
         L.mcgp_run.restype = C.c_int32
         L.mcgp_run.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), dp, C.c_uint32, C.c_uint64,
                                C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
+        if hasattr(L, 'mcgp_run_batch'):
+            L.mcgp_run_batch.restype = C.c_int32
+            L.mcgp_run_batch.argtypes = [C.c_uint32, C.POINTER(McgpConfig), C.POINTER(McgpDrivers), C.POINTER(dp), C.c_uint32,
+                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32,
+                                         C.POINTER(C.c_uint64)]
         L.mcgp_run_device.restype = C.c_int32
         L.mcgp_run_device.argtypes = [C.POINTER(McgpConfig), C.POINTER(McgpDrivers), dp, C.c_uint32, C.c_uint64,
                                       C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

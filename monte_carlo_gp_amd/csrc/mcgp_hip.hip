@@ -163,6 +163,10 @@ struct DeviceCtx {
     int last_timer = -1;
     unsigned char *d_elo = nullptr;         // scratch of mcgp_elo_season (grow-only)
     size_t elo_bytes = 0;
+    unsigned char *d_batch = nullptr;       // mcgp_run_batch: parameter blocks, items, histograms, ticket (grow-only)
+    size_t batch_bytes = 0;
+    uint32_t *d_batch_retire = nullptr;     // ... and the lanes' retirement lists
+    size_t batch_retire_bytes = 0;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     char last_kernel[48] = "";
 };
@@ -210,6 +214,11 @@ void release_ctx(DeviceCtx &c)
     if (c.d_elo) (void)hipFree(c.d_elo);
     c.d_elo = nullptr;
     c.elo_bytes = 0;
+    if (c.d_batch) (void)hipFree(c.d_batch);
+    if (c.d_batch_retire) (void)hipFree(c.d_batch_retire);
+    c.d_batch = nullptr;
+    c.d_batch_retire = nullptr;
+    c.batch_bytes = c.batch_retire_bytes = 0;
     for (auto &t : c.timer) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
@@ -287,9 +296,25 @@ namespace mcgp {
                                                                   uint32_t *, uint32_t *);
 MCGP_REG_SIZES(X)
 #undef X
+#define X(N_) extern template __global__ void race_kernel_reg_batch<N_>(const KParams *, const BatchItem *, uint32_t, uint64_t, \
+                                                                        unsigned long long *, uint32_t, uint32_t *, uint32_t *);
+MCGP_REG_SIZES(X)
+#undef X
 }  // namespace mcgp
 
 namespace {
+
+using BatchKernelFn = void (*)(const mcgp::KParams *, const mcgp::BatchItem *, uint32_t, uint64_t, unsigned long long *,
+                               uint32_t, uint32_t *, uint32_t *);
+BatchKernelFn select_batch_kernel(uint32_t n)
+{
+    switch (n) {
+#define X(N_) case N_: return &mcgp::race_kernel_reg_batch<N_>;
+        MCGP_REG_SIZES(X)
+#undef X
+        default: return nullptr;
+    }
+}
 
 KernelFn select_kernel(const mcgp::KParams &kp, bool *is_reg)
 {
@@ -800,6 +825,107 @@ int32_t mcgp_run_from_ratings(const mcgp_config *cfg, const mcgp_drivers *drv, c
     rc = body();
     delete kp;
     return rc;
+}
+
+int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_drivers *drvs,
+                       const double *const *grid_probs, uint32_t n, uint64_t n_sims, const uint64_t *sim_offsets,
+                       const uint64_t *seeds, int32_t device, uint64_t *hist_out)
+{
+    if (!cfgs || !drvs || !grid_probs || !seeds || !hist_out) return fail(MCGP_E_BAD_ARG, "a batch array is NULL");
+    if (n_problems < 1 || n_problems > 4096) return fail(MCGP_E_BAD_ARG, "n_problems must be in [1, 4096]");
+    if (n_sims >= 0xFFFFFE00ull) return fail(MCGP_E_BAD_ARG, "n_sims per problem must be below 2^32 - 512 in a batch");
+    if (n_sims == 0) return MCGP_OK;
+    std::vector<mcgp::KParams> kps(n_problems);
+    std::vector<mcgp::BatchItem> items(n_problems);
+    for (uint32_t p = 0; p < n_problems; ++p) {
+        if (!grid_probs[p]) return fail(MCGP_E_BAD_ARG, "a grid_probs pointer of the batch is NULL");
+        const int rc = build_params(&cfgs[p], &drvs[p], grid_probs[p], n, &kps[p]);
+        if (rc != MCGP_OK) return rc;
+        // the batch kernel is the register kernel; a problem only the generic kernel takes (lap times near zero, values
+        // near the ends of binary64) is refused rather than silently run elsewhere: use mcgp_run for it
+        if (!mcgp::reg_kernel_serves(kps[p]))
+            return fail(MCGP_E_BAD_ARG, "a problem of the batch is outside the register kernel's domain (see reg_kernel_serves): run it with mcgp_run");
+        items[p].sim_offset = sim_offsets ? sim_offsets[p] : 0ull;
+        items[p].seed = seeds[p];
+    }
+    const BatchKernelFn kernel = select_batch_kernel(n);
+    if (!kernel) return fail(MCGP_E_BAD_ARG, "no batch kernel for this field size");
+    DeviceCtx *c = nullptr;
+    int rc = find_ctx(device, &c);
+    if (rc != MCGP_OK) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto body = [&]() -> int {
+        int r = ensure_ctx_locked(device, *c);
+        if (r != MCGP_OK) return r;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)c->lds_per_block));
+        // geometry: the register kernel's block, one more LDS word for the task hand-over
+        const int waves = mcgp::reg_block_waves((int)n);
+        const uint32_t block = (uint32_t)waves * 64u;
+        const size_t lds = mcgp::shared_lds_bytes_reg((int)n) + (size_t)block * mcgp::per_thread_lds_bytes_reg((int)n) +
+                           mcgp::kBatchLdsExtra;
+        int reg_cap = 4 * mcgp::reg_min_waves((int)n);
+        int blocks_per_cu = (int)(c->lds_per_block / lds);
+        if (blocks_per_cu * waves > reg_cap) blocks_per_cu = reg_cap / waves;
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+        const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
+        const uint64_t n_tasks = (uint64_t)n_problems * ((n_chunks + (uint32_t)waves - 1) / (uint32_t)waves);
+        if (n_tasks >= 0xFFFF0000ull) return fail(MCGP_E_BAD_ARG, "batch too large for one launch");
+        uint64_t grid = (uint64_t)c->cu_count * (uint64_t)blocks_per_cu;
+        if (grid > n_tasks) grid = n_tasks;
+        // one device buffer: [parameter blocks | items | histograms | ticket]
+        const size_t o_items = sizeof(mcgp::KParams) * n_problems;
+        const size_t o_hist = o_items + sizeof(mcgp::BatchItem) * n_problems;
+        const size_t hist_bytes = sizeof(unsigned long long) * n * n * n_problems;
+        const size_t o_ticket = o_hist + hist_bytes;
+        const size_t bytes = o_ticket + 16;
+        if (bytes > c->batch_bytes) {
+            if (c->d_batch) (void)hipFree(c->d_batch);
+            c->d_batch = nullptr;
+            c->batch_bytes = 0;
+            HIP_TRY(hipMalloc(&c->d_batch, bytes));
+            c->batch_bytes = bytes;
+        }
+        const size_t ws = mcgp::reg_retire_ws_bytes((int)n, (size_t)grid * block);
+        if (ws > c->batch_retire_bytes) {
+            if (c->d_batch_retire) (void)hipFree(c->d_batch_retire);
+            c->d_batch_retire = nullptr;
+            c->batch_retire_bytes = 0;
+            HIP_TRY(hipMalloc(&c->d_batch_retire, ws));
+            c->batch_retire_bytes = ws;
+        }
+        unsigned char *d = c->d_batch;
+        HIP_TRY(hipMemcpyAsync(d, kps.data(), o_items, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(d + o_items, items.data(), sizeof(mcgp::BatchItem) * n_problems, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipMemsetAsync(d + o_hist, 0, hist_bytes + 16, nullptr));
+        // timed like the other launches (the default stream's entry)
+        int ti = -1;
+        for (int i = 0; i < kStreamTimers; ++i)
+            if (c->timer[i].used && c->timer[i].stream == nullptr) { ti = i; break; }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ti >= 0) { e0 = c->timer[ti].start; e1 = c->timer[ti].stop; }
+        if (e0) HIP_TRY(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(block), lds, nullptr,
+                           reinterpret_cast<const mcgp::KParams *>(d), reinterpret_cast<const mcgp::BatchItem *>(d + o_items),
+                           n_problems, n_sims, reinterpret_cast<unsigned long long *>(d + o_hist), n_chunks,
+                           reinterpret_cast<uint32_t *>(d + o_ticket), c->d_batch_retire);
+        HIP_TRY(hipGetLastError());
+        if (e1) {
+            HIP_TRY(hipEventRecord(e1, nullptr));
+            c->timer[ti].seq = ++c->timer_seq;
+            c->last_timer = ti;
+        }
+        std::vector<unsigned long long> h((size_t)n * n * n_problems);
+        HIP_TRY(hipMemcpy(h.data(), d + o_hist, hist_bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); ++i) hist_out[i] += h[i];
+        c->last_grid = (uint32_t)grid;
+        c->last_block = block;
+        c->last_lds = (uint32_t)lds;
+        std::snprintf(c->last_kernel, sizeof(c->last_kernel), "mcgp::race_kernel_reg_batch<%u>", n);
+        return MCGP_OK;
+    };
+    return body();
 }
 
 int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out)

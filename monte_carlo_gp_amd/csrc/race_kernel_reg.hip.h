@@ -469,9 +469,6 @@ __host__ __device__ inline double reg_time_floor(const KParams &kp)
 // race_common.hip.h), where a probability >= 1 is just a survival threshold of 0.
 __host__ __device__ inline bool reg_kernel_serves(const KParams &kp)
 {
-    // an overtake attempt is told from its threshold being non-zero, which wants overtake_delta >= 0 (dl > delta >= 0
-    // makes ceil(dl 2^31) >= 1); a negative delta -- attempts at a pace DEFICIT -- is the generic kernel's
-    if (!(kp.overtake_delta >= 0.0)) return false;
     // The kernel's tables carry powers of two (pace x 2^31, degradation x 2^-16 or x 2^15): exact, a power of two
     // commutes with every rounding, unless the scaled value leaves the normal range.  Magnitudes no race has, but the
     // kernel is bit-exact on what it accepts: anything near the ends of binary64 goes to the generic kernel.
@@ -553,6 +550,8 @@ __device__ __forceinline__ void reg_flush_hist(unsigned char *smem, uint32_t tid
     }
 }
 
+constexpr uint32_t kTicketChunks = 0xFFFFFFFFu;      // reg_simulate: "claim chunks from the ticket counter"
+
 // Phase 2: the simulations, one full race per lane.  The unit of work is a WAVE-CHUNK of 64 consecutive simulations,
 // and every wave of the launch claims its next chunk from one ticket counter in device memory (zeroed by the host
 // before the launch) until the chunks run out: a wave that runs faster than its neighbours takes more of them instead
@@ -566,7 +565,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                              uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
                                              uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid,
                                              uint32_t n_chunks, uint32_t *__restrict__ retire_ws_base, uint32_t ws_stride,
-                                             uint32_t ws_first_lane)
+                                             uint32_t ws_first_lane, uint32_t fixed_chunk = kTicketChunks)
 {
     using G = RegGeo<N>;
     constexpr int B = G::B;
@@ -616,7 +615,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     };
 
     for (uint32_t turn = 0u;; ++turn) {
-        const uint32_t chunk = next_ticket(ticket, tid, turn, G::kWaves);
+        // (a batch launch hands every wave ONE chunk of the block's current problem instead: race_kernel_reg_batch)
+        if (fixed_chunk != kTicketChunks && turn > 0u) break;
+        const uint32_t chunk = fixed_chunk != kTicketChunks ? fixed_chunk : next_ticket(ticket, tid, turn, G::kWaves);
         if (chunk >= n_chunks) break;                            // (every wave ends on its first ticket past the end)
         const uint64_t local = (uint64_t)chunk * 64ull + (uint64_t)(tid & 63u);
         // A lane past the end of the run still runs a race while any lane of its wave has one to run -- the wave's
@@ -1244,10 +1245,22 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // A wave with a lane that has more than eight attempts takes the general path, 8 attempts at a time, and
                 // leaves its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
                 if (__builtin_expect(MCGP_ANY(words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
-                    // the candidate mask: a candidate's threshold is at least 1 (dl > overtake_delta >= 0, reg_kernel_serves)
+                    // the candidate mask, worked out again from the pace deltas (a threshold of 0 does not tell "no attempt"
+                    // from "an attempt that cannot succeed", which a negative overtake_delta allows)
                     uint32_t cand = 0u;
+                    {
+                        double pace_prev = 0.0;
 #pragma unroll
-                    for (int i = 1; i < N; ++i) cand |= thr[i] != 0u ? (1u << i) : 0u;
+                        for (int i = 0; i < N; ++i) {
+                            const f64x2 bd = lds_ld_f64x2(G::oDrvB + ((pk[i] >> 6) & 0x3F0u));
+                            const double pace = bd.x + (double)(pk[i] & k3AgeMask) * bd.y;
+                            if (i > 0) {
+                                const double dl = (pace_prev - pace) + lds_ld<double>(G::oDrsB + (pk[i] & k3Drs));
+                                cand |= dl > od31 ? (1u << i) : 0u;
+                            }
+                            pace_prev = pace;
+                        }
+                    }
                     uint32_t hits = 0u, rest = cand;
 #pragma unroll 1
                     for (int chunk = 0; rest != 0u; ++chunk) {
@@ -1372,5 +1385,52 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     __syncthreads();
     reg_flush_hist<N>(smem, threadIdx.x, hist);
 }
+
+// ---- several problems in one launch (mcgp_run_batch) ----
+// The reference predicts a race from 10 000 simulations (reference src/predictor.py:284) and a backtest runs two dozen
+// races one after the other (src/validation.py:179-185): at that size a launch is as long as ONE race of one lane and the
+// device is mostly idle, so the races of a sweep go into one launch.  The block-shared tables belong to one problem, so
+// the unit of work is a block-task: (problem, group of kWaves consecutive chunks); blocks claim tasks from the launch's
+// ticket counter, reload the tables when the problem changes, and every wave runs the task's chunk that falls to it.
+// Per-problem inputs that are not in the parameter block:
+struct BatchItem {
+    uint64_t sim_offset, seed;
+};
+template <int N>
+__global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
+race_kernel_reg_batch(const KParams *__restrict__ P, const BatchItem *__restrict__ items, uint32_t n_problems,
+                      uint64_t n_sims, unsigned long long *__restrict__ hist, uint32_t n_chunks,
+                      uint32_t *__restrict__ ticket, uint32_t *__restrict__ retire_ws)
+{
+    using G = RegGeo<N>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((int)blockDim.x != G::B || lds_base_of(smem) != 0u) __builtin_trap();
+    const uint32_t groups = (n_chunks + (uint32_t)G::kWaves - 1u) / (uint32_t)G::kWaves;     // block-tasks per problem
+    const uint32_t n_tasks = n_problems * groups;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t cur = 0xFFFFFFFFu;                                  // the problem whose tables are in LDS
+    for (;;) {
+        // one thread claims the block's next task; the word just past the kernel's LDS map carries it to the others
+        if (threadIdx.x == 0) lds_st<uint32_t>(G::kBytes, atomicAdd(ticket, 1u));
+        __syncthreads();
+        const uint32_t task = lds_ld<uint32_t>(G::kBytes);
+        if (task >= n_tasks) break;
+        const uint32_t p = task / groups, group = task % groups;
+        if (p != cur) {
+            if (cur != 0xFFFFFFFFu) reg_flush_hist<N>(smem, threadIdx.x, hist + (size_t)cur * N * N);
+            __syncthreads();                                     // (flush reads the LDS histogram the table load zeroes)
+            reg_load_tables<N>(P + p, smem, threadIdx.x);
+            __syncthreads();
+            cur = p;
+        }
+        const BatchItem it = items[p];
+        reg_simulate<N>(P + p, smem, threadIdx.x, nullptr, n_sims, it.sim_offset, (uint32_t)it.seed, (uint32_t)(it.seed >> 32),
+                        nullptr, nullptr, n_chunks, retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B),
+                        group * (uint32_t)G::kWaves + wave);
+        __syncthreads();                                         // every wave's counts are in before a flush or a reload
+    }
+    if (cur != 0xFFFFFFFFu) reg_flush_hist<N>(smem, threadIdx.x, hist + (size_t)cur * N * N);
+}
+constexpr size_t kBatchLdsExtra = 16;                            // the task word
 
 }  // namespace mcgp

@@ -24,38 +24,11 @@ from __future__ import annotations
 
 import ctypes as C
 import random
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 
 from . import _native as N
-
-
-@dataclass
-class CarState:
-    """Per-car state of one simulation (reference :9-34); kept for interface parity.
-
-    On the device a car is a slot of two register arrays (time, packed state word) of its simulation's lane,
-    see csrc/race_kernel_reg.hip.h.
-    """
-    driver: str
-    team: str
-    position: int
-    lap: int
-    tire_compound: str
-    tire_age: int
-    fuel_load: float
-    time_behind_leader: float
-    pit_stops: int
-    cumulative_time: float = 0.0
-    drs_enabled: bool = False
-    dnf: bool = False
-    used_compounds: set = field(default_factory=set)
-    laps_completed: int = 0
-    last_lap_time: float = 0.0
-
-    def __post_init__(self):
-        self.used_compounds.add(self.tire_compound)
 
 
 @dataclass
@@ -133,9 +106,29 @@ class _Problem:
 class RaceSimulator:
     """Drop-in for the reference's RaceSimulator (:55-560) with the race loop on the GPU."""
 
-    def __init__(self, config: RaceConfig, device: int = 0, set_pop: dict | None = None):
+    def __init__(self, config: RaceConfig, device=0, set_pop: dict | None = None):
+        """`device`: a HIP device index (default 0), a list of indices, or 'all' (every visible device).  With more
+        than one device a run_monte_carlo call is split by simulation id into contiguous shards, one host thread per
+        device over the same C entry point, and the integer histograms are added on the host -- the whole node from the
+        plain single-process call the reference's caller makes (reference src/predictor.py:264,283-291), with results
+        identical to a one-device run (every draw is a function of the global simulation id).  An index may be
+        listed more than once (shards then queue on that device).  The torchrun + RCCL path (distributed.py) is
+        separate and unchanged."""
         self.config = config
-        self.device = int(device)
+        if isinstance(device, str):
+            if device != 'all':
+                raise ValueError(f"device must be an index, a list of indices or 'all', got {device!r}")
+            count = N.lib().mcgp_device_count()
+            if count < 1:
+                raise N.McgpError(-2, 'no HIP device visible (this library has no CPU path)')
+            self.devices = list(range(count))
+        elif isinstance(device, (list, tuple)):
+            if not device:
+                raise ValueError('device list is empty')
+            self.devices = [int(d) for d in device]
+        else:
+            self.devices = [int(device)]
+        self.device = self.devices[0]        # single-device entry points (simulate_race, the front end) use the first
         self.set_pop = dict(set_pop or DEFAULT_SET_POP)
         self.last_histogram = None      # np.int64 [n, n], counts[driver][position-1] of the last run
         self.last_drivers = None
@@ -196,12 +189,32 @@ class RaceSimulator:
         prob = self._problem(drivers, base_pace, tire_deg, driver_variance, driver_dnf_rates, track_condition)
         n = prob.n
         g = self._grid_matrix({str(k): v for k, v in grid_probs.items()}, drivers)
-        hist = np.zeros((n, n), np.uint64)
         orders = np.zeros((n_simulations, n), np.uint8) if return_orders else None
-        N.check(N.lib().mcgp_run(
-            C.byref(prob.cfg), C.byref(prob.drv), _dptr(g), n, int(n_simulations), int(sim_offset),
-            self._resolve_seed(seed), self.device, hist.ctypes.data_as(C.POINTER(C.c_uint64)),
-            orders.ctypes.data_as(C.POINTER(C.c_uint8)) if return_orders else None))
+        seed64 = self._resolve_seed(seed)
+        lib = N.lib()
+
+        def run_shard(device, offset, count):
+            h = np.zeros((n, n), np.uint64)
+            o = orders[offset:offset + count] if return_orders else None       # contiguous rows of the caller's buffer
+            rc = lib.mcgp_run(C.byref(prob.cfg), C.byref(prob.drv), _dptr(g), n, int(count), int(sim_offset) + int(offset),
+                              seed64, device, h.ctypes.data_as(C.POINTER(C.c_uint64)),
+                              o.ctypes.data_as(C.POINTER(C.c_uint8)) if return_orders else None)
+            # (mcgp_last_error is thread-local: read it on the thread that made the call)
+            return h, rc, (lib.mcgp_last_error().decode('utf-8', 'replace') if rc != 0 else '')
+
+        if len(self.devices) == 1:
+            parts = [run_shard(self.devices[0], 0, int(n_simulations))]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            from .distributed import shard_range
+            world = len(self.devices)
+            shards = [shard_range(int(n_simulations), k, world) for k in range(world)]
+            with ThreadPoolExecutor(world) as ex:          # ctypes releases the GIL for the duration of the call
+                parts = list(ex.map(lambda a: run_shard(a[0], *a[1]), zip(self.devices, shards)))
+        for _, rc, msg in parts:
+            if rc != 0:
+                raise N.McgpError(rc, msg)
+        hist = np.sum([h for h, _, _ in parts], axis=0, dtype=np.uint64)
         self.last_histogram = hist.astype(np.int64)
         self.last_drivers = drivers
         result = histogram_to_probs(self.last_histogram, drivers, n_simulations)
@@ -288,6 +301,49 @@ class RaceSimulator:
                                        track_condition='dry')
         return self.run_monte_carlo(n_sims, grid, ri['base_pace'], ri['tire_deg'], ri['driver_variance'],
                                     ri['driver_dnf_rates'], seed=seed, track_condition=ri['track_condition'])
+
+
+def run_monte_carlo_batch(problems, n_simulations, device=0, set_pop=None):
+    """Several races in ONE launch (include/mcgp.h: mcgp_run_batch): what a backtest of the reference does race after
+    race (reference src/validation.py:179-185, 10 000 simulations each, src/predictor.py:284) -- at that size a launch
+    is as long as one race of one lane, and a season fits beside itself on the device.
+
+    `problems`: a list of dicts with the keys `config` (RaceConfig) and run_monte_carlo's arguments `grid_probs`,
+    `base_pace`, `tire_deg`, `driver_variance`, and optionally `driver_dnf_rates`, `seed`, `track_condition`,
+    `sim_offset`.  Returns a list of (probabilities as run_monte_carlo returns them, integer histogram [n, n]), one
+    per problem and bit-identical to running it alone.  Races of different field sizes go into one launch per size."""
+    set_pop = dict(set_pop or DEFAULT_SET_POP)
+    lib = N.lib()
+    n_simulations = int(n_simulations)
+    prepared = []
+    for pr in problems:
+        drivers = [str(d) for d in pr['grid_probs'].keys()]
+        if not (1 <= len(drivers) <= N.MAX_CARS):
+            raise ValueError(f'number of drivers must be in [1, {N.MAX_CARS}], got {len(drivers)}')
+        prob = _Problem(pr['config'], drivers, pr['base_pace'], pr['tire_deg'], pr['driver_variance'],
+                        pr.get('driver_dnf_rates'), pr.get('track_condition', 'dry'), set_pop)
+        g = RaceSimulator._grid_matrix({str(k): v for k, v in pr['grid_probs'].items()}, drivers)
+        prepared.append((prob, g, RaceSimulator._resolve_seed(pr.get('seed')), int(pr.get('sim_offset', 0))))
+    out = [None] * len(prepared)
+    if n_simulations <= 0:
+        return [({}, np.zeros((p.n, p.n), np.int64)) for p, _, _, _ in prepared]
+    by_n = {}
+    for i, item in enumerate(prepared):
+        by_n.setdefault(item[0].n, []).append(i)
+    for n, idx in by_n.items():
+        k = len(idx)
+        cfgs = (N.McgpConfig * k)(*[prepared[i][0].cfg for i in idx])
+        drvs = (N.McgpDrivers * k)(*[prepared[i][0].drv for i in idx])
+        grids = (C.POINTER(C.c_double) * k)(*[_dptr(prepared[i][1]) for i in idx])
+        seeds = (C.c_uint64 * k)(*[prepared[i][2] for i in idx])
+        offsets = (C.c_uint64 * k)(*[prepared[i][3] for i in idx])
+        hist = np.zeros((k, n, n), np.uint64)
+        N.check(lib.mcgp_run_batch(k, cfgs, drvs, grids, n, n_simulations, offsets, seeds, int(device),
+                                   hist.ctypes.data_as(C.POINTER(C.c_uint64))))
+        for j, i in enumerate(idx):
+            h = hist[j].astype(np.int64)
+            out[i] = (histogram_to_probs(h, prepared[i][0].drivers, n_simulations), h)
+    return out
 
 
 def histogram_to_probs(hist, drivers, n_simulations):

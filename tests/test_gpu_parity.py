@@ -343,3 +343,68 @@ def test_orders_into_an_unaligned_device_buffer(require_gpu):
         assert (raw[:shift] == 0xEE).all() and (raw[shift + n_sims * p.n:] == 0xEE).all(), shift     # nothing written outside
     ok(hip.hipFree(d_hist))
     ok(hip.hipFree(d_orders))
+
+
+def test_whole_node_from_the_drop_in_call_three_shards_on_one_device(require_gpu):
+    """RaceSimulator(config, device=[...]): the plain single-process call of the reference's caller (reference
+    src/predictor.py:264,283-291) split over several devices by simulation id, one host thread per device, histograms
+    added on the host.  With one GPU in the box the list names it three times: three concurrent shards
+    (ragged: 5000 = 1667 + 1667 + 1666) must give the single-device result and the oracle's, finishing orders included;
+    device='all' must resolve to the visible devices.  More than one physical device: unmeasured on hardware."""
+    from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N
+    case = O.load_case('S60')
+    n_sims, seed = 5000, 1234
+    ref = O.Problem(case).run(n_sims, rng=O.RNG_PHILOX, seed=seed, sim_offset=77, want_orders=True)
+    cfg = RaceConfig(**case['config'])
+    args = (case['grid_probs'], case['base_pace'], case['tire_deg'], case['driver_variance'], case['driver_dnf_rates'])
+    for device in (0, [0, 0, 0], 'all'):
+        sim = RaceSimulator(cfg, device=device, set_pop=O.load_cases()['set_pop'])
+        probs, orders = sim.run_monte_carlo(n_sims, *args, seed=seed, track_condition=case['track_condition'],
+                                            sim_offset=77, return_orders=True)
+        assert np.array_equal(sim.last_histogram, ref['hist']), device
+        assert np.array_equal(orders, ref['orders']), device
+        assert abs(sum(probs[list(probs)[0]].values()) - 1.0) < 1e-12
+    assert RaceSimulator(cfg, device='all').devices == list(range(N.lib().mcgp_device_count()))
+    with pytest.raises(N.McgpError):
+        RaceSimulator(cfg, device=[0, 99]).run_monte_carlo(100, *args, seed=1)      # a shard's error reaches the caller
+
+
+def test_a_season_of_races_in_one_launch(require_gpu):
+    """mcgp_run_batch: 24 races x 10 000 simulations -- the reference's own size (reference
+    src/predictor.py:284, backtest loop src/validation.py:179-185) -- in ONE launch, plus races of two other field sizes
+    (one launch per size).  Every race's histogram equals the oracle's and what mcgp_run gives for it alone; the GPU time
+    of the 24-race launch is recorded (a single race of this size is one ~1.8 ms launch: 24 of them back to back ~44 ms)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from monte_carlo_gp_amd import RaceConfig, run_monte_carlo_batch, _native as N
+    names = ['S60', 'S78', 'S50', 'EVT', 'DMP', 'WET']
+    cases = {k: O.load_case(k) for k in names + ['HET', 'N10']}
+    assert all(len(cases[k]['grid_probs']) == 20 for k in names)
+    plan = [(names[i % 6], 1000 + 17 * i, 5 * i) for i in range(24)] + [('HET', 5, 0), ('N10', 6, 3), ('HET', 7, 11)]
+    n_sims = 10_000
+
+    def problem(name, seed, off):
+        c = cases[name]
+        return dict(config=RaceConfig(**c['config']), grid_probs=c['grid_probs'], base_pace=c['base_pace'],
+                    tire_deg=c['tire_deg'], driver_variance=c['driver_variance'], driver_dnf_rates=c['driver_dnf_rates'],
+                    seed=seed, track_condition=c['track_condition'], sim_offset=off)
+    set_pop = O.load_cases()['set_pop']
+    out = run_monte_carlo_batch([problem(*p) for p in plan], n_sims, device=0, set_pop=set_pop)
+    with ThreadPoolExecutor(8) as ex:
+        refs = list(ex.map(lambda p: O.Problem(cases[p[0]]).run(n_sims, rng=O.RNG_PHILOX, seed=p[1], sim_offset=p[2])['hist'], plan))
+    for (name, seed, off), (probs, hist), ref in zip(plan, out, refs):
+        assert np.array_equal(hist, ref), (name, seed)
+        assert (hist.sum(axis=0) == n_sims).all() and (hist.sum(axis=1) == n_sims).all()
+    alone = product_run(cases['EVT'], n_sims, plan[3][1], sim_offset=plan[3][2])[0]
+    assert np.array_equal(alone, out[3][1])
+    # the 24-race launch on its own, timed by the library's events
+    run_monte_carlo_batch([problem(*p) for p in plan[:24]], n_sims, device=0, set_pop=set_pop)
+    ms = C.c_float()
+    N.check(N.lib().mcgp_last_kernel_ms(0, C.byref(ms)))
+    name = N.lib().mcgp_last_kernel_name(0).decode()
+    print(f'\nbatch of 24 x {n_sims}: kernel {name} {ms.value:.3f} ms')
+    assert name == 'mcgp::race_kernel_reg_batch<20>'
+    assert ms.value < 8.0            # two rounds of races (3750 wave-chunks on 3072 wave slots), not 24
+    # empty and degenerate batches
+    assert run_monte_carlo_batch([], n_sims) == []
+    assert run_monte_carlo_batch([problem('S60', 1, 0)], 0)[0][0] == {}

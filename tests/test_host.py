@@ -182,3 +182,16 @@ def test_a_stale_library_is_refused(tmp_path):
                              timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.startswith('refused:') and '0123456789abcdef' in out.stdout, (mode, out.stdout)
+
+
+def test_device_argument_of_the_drop_in_class():
+    cfg = RaceConfig(**O.load_case('S60')['config'])
+    assert RaceSimulator(cfg).devices == [0] and RaceSimulator(cfg, device=3).devices == [3]
+    assert RaceSimulator(cfg, device=[1, 0, 1]).devices == [1, 0, 1] and RaceSimulator(cfg, device=(2,)).device == 2
+    with pytest.raises(ValueError):
+        RaceSimulator(cfg, device=[])
+    with pytest.raises(ValueError):
+        RaceSimulator(cfg, device='every')
+    if N.lib().mcgp_device_count() == 0:
+        with pytest.raises(N.McgpError):
+            RaceSimulator(cfg, device='all')                # no CPU path, no silent empty device list
