@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define MCGP_ABI_VERSION 1
+/* 2: mcgp_build_hash, mcgp_run_batch; the retirement draw of laps >= 2 moved to one word per driver and race, which
+ * changes the results for a given seed (the oracle's Philox back-end moved with it) */
+#define MCGP_ABI_VERSION 2
 #define MCGP_MAX_CARS 32
 #define MCGP_MAX_LAPS 1000
 
@@ -118,8 +120,11 @@ int32_t mcgp_run(const mcgp_config *cfg, const mcgp_drivers *drv, const double *
  * EVERY stream that used it have completed.  Runs of 2^32 simulations or more are split into several launches
  * on the stream (the per-block histogram counts in 32 bits).  Every launch is preceded, on the same stream, by a
  * 4-byte memset of the stream's work counter (the kernel's waves claim their simulations from it; the library
- * keeps a counter per stream, 8 per device, and recycles the least recently used one behind its last launch):
- * what the call enqueues is {upload if the block changed, memset, kernel} per launch, all capturable.  Results do
+ * keeps a counter per stream, 8 per device, and recycles the least recently used one behind its last launch).
+ * The call itself is NOT capturable into a hipGraph: on a stream's first use it creates events and allocates the
+ * counter and the kernel's per-lane scratch, a recycled counter or an evicted parameter block is waited for on the
+ * host, and a captured graph would keep a counter the library may later hand to another stream.  A step is one
+ * memset + one kernel of ~75 ms at bench size, so there is no launch overhead for a graph to remove.  Results do
  * not depend on which wave ran which simulation. */
 int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs,
                         uint32_t n, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, 'libmcgp_hip.so')
 
 MAX_CARS = 32
 MAX_LAPS = 1000
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 COMPOUNDS = ('SOFT', 'MEDIUM', 'HARD', 'INTERMEDIATE', 'WET')
 COMPOUND_ID = {c: i for i, c in enumerate(COMPOUNDS)}

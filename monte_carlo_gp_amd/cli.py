@@ -162,6 +162,9 @@ def shard_jobs(jobs, rank, world):
     return [(i, j) for i, j in enumerate(jobs) if i % world == rank]
 
 
+BATCH_MAX_SIMULATIONS = 1_000_000        # per race: up to here the races of a sweep share one launch
+
+
 def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, predictor_factory=None,
              fixtures_dir=None):
     """Sweep one prediction per race of each season and score it (reference validation.py:161-209).
@@ -175,10 +178,24 @@ def backtest(seasons, seed=42, n_simulations=10000, device=0, rank=0, world=1, p
     """
     mine = shard_jobs(backtest_jobs(seasons, seed, fixtures_dir), rank, world)
     factory = predictor_factory or (lambda: F1Predictor(device=device))
+    # At the reference's size (10 000 simulations per race, src/predictor.py:284) a launch is as long as one race of
+    # one lane: this rank's races then go to the device in ONE launch (run_monte_carlo_batch; every race's histogram is
+    # what its own launch would give).  Above BATCH_MAX_SIMULATIONS a race fills the device by itself.
+    batched = {}
+    if predictor_factory is None and 0 < n_simulations <= BATCH_MAX_SIMULATIONS and mine:
+        from .predictor import pack_result
+        from .simulation import run_monte_carlo_batch
+        todo = [(i, job) for i, job in mine if job[3].get('drivers')]       # (a weekend without data raises below, as ever)
+        inputs = [F1Predictor(device=device).simulator_inputs(fixture, entry['race'])
+                  for _, (season, entry, race_seed, fixture) in todo]
+        outs = run_monte_carlo_batch([dict(inp, seed=job[2]) for inp, (_, job) in zip(inputs, todo)], n_simulations,
+                                     device=device)
+        for (i, _), inp, (probs, _) in zip(todo, inputs, outs):
+            batched[i] = pack_result(inp['drivers'], inp['grid_probs'], probs, inp['weather'], 'fp2', None)
     rows = []
     for i, (season, entry, race_seed, fixture) in mine:
-        res = factory().predict_weekend(season, entry['race'], fixture, n_simulations=n_simulations,
-                                        seed=race_seed)
+        res = batched[i] if i in batched else factory().predict_weekend(
+            season, entry['race'], fixture, n_simulations=n_simulations, seed=race_seed)
         rows.append((i, dict(race=entry['race'], season=season, laps=circuit_info(entry['race'])['laps'],
                              pole=res['pole_probabilities'], win=res['win_probabilities'],
                              podium_probabilities=res['podium_probabilities'], actual=entry, seed=race_seed,

@@ -133,6 +133,7 @@ struct DeviceCtx {
             hipStream_t stream = nullptr;
             hipEvent_t done = nullptr;        // recorded after that stream's last launch reading `dev`
             bool live = false;
+            uint64_t seq = 0;                 // order of the last launch through this entry
         } reader[kSlotReaders];
         hipEvent_t uploaded = nullptr;        // recorded after the upload of `dev`; other streams wait on it
         hipStream_t upload_stream = nullptr;
@@ -453,10 +454,23 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
             if (!c.timer[i].used) { ti = i; break; }
             if (c.timer[i].seq < c.timer[ti].seq) ti = i;
         }
-        if (!c.timer[ti].start) {
-            HIP_TRY(hipEventCreate(&c.timer[ti].start));
-            HIP_TRY(hipEventCreate(&c.timer[ti].stop));
-            HIP_TRY(hipMalloc(&c.timer[ti].d_ticket, sizeof(uint32_t)));
+        if (!c.timer[ti].d_ticket) {
+            // events and counter are created into locals and committed together: a failure part-way leaves the entry
+            // empty (not an entry with events and a NULL counter for the next launch to hand to the kernel)
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            uint32_t *tk = nullptr;
+            hipError_t err = hipEventCreate(&e0);
+            if (err == hipSuccess) err = hipEventCreate(&e1);
+            if (err == hipSuccess) err = hipMalloc(&tk, sizeof(uint32_t));
+            if (err != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                return fail(err == hipErrorOutOfMemory ? MCGP_E_NOMEM : MCGP_E_HIP,
+                            std::string("stream timer / work counter: ") + hipGetErrorString(err));
+            }
+            c.timer[ti].start = e0;
+            c.timer[ti].stop = e1;
+            c.timer[ti].d_ticket = tk;
         } else if (c.timer[ti].used) {
             // recycled from another stream: its last launch may still be claiming work from the entry's counter
             HIP_TRY(hipEventSynchronize(c.timer[ti].stop));
@@ -465,6 +479,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         c.timer[ti].used = true;
     }
     c.timer[ti].seq = ++c.timer_seq;
+    if (!c.timer[ti].d_ticket) return fail(MCGP_E_HIP, "no work counter for this stream");
     HIP_TRY(hipEventRecord(c.timer[ti].start, stream));
     const uint64_t cap = max_sims_per_launch();
     uint32_t grid = 0, block = 0, lds = 0;
@@ -505,11 +520,16 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         DeviceCtx::Slot::Reader *rd = nullptr, *spare = nullptr;
         for (auto &r : sl->reader) {
             if (r.live && r.stream == stream) { rd = &r; break; }
+            // an entry whose launch has completed is free again (it used to stay "live" until the block was evicted,
+            // so that the ninth stream on a long-lived block blocked the host on entry 0 -- the most recent launch)
+            if (r.live && hipEventQuery(r.done) == hipSuccess) r.live = false;
             if (!r.live && !spare) spare = &r;
         }
         if (!rd) {
-            if (!spare) {                               // more streams in flight than entries: retire the first
+            if (!spare) {                               // more streams IN FLIGHT than entries: wait for the oldest launch
                 spare = &sl->reader[0];
+                for (auto &r : sl->reader)
+                    if (r.seq < spare->seq) spare = &r;
                 HIP_TRY(hipEventSynchronize(spare->done));
             }
             rd = spare;
@@ -517,6 +537,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
             rd->stream = stream;
             rd->live = true;
         }
+        rd->seq = c.timer_seq;
         HIP_TRY(hipEventRecord(rd->done, stream));
     }
     c.last_grid = grid;

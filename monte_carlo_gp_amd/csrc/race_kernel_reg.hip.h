@@ -98,7 +98,7 @@ __host__ __device__ constexpr size_t shared_lds_bytes_reg(int n)
 {
     return (size_t)kNormalRows * 16 + (size_t)n * 16 + (size_t)(kMaxCars + n) * 16 +
            (size_t)((kNumCompounds - 1) * kMaxCars + n) * 16 + kCompStride * 16 + 64 + 128 + align16((size_t)n * n * 4) +
-           (size_t)n * n * 8;
+           align16((size_t)n * n * 8);      // (16-byte multiple: the per-lane planes that follow are accessed 16 bytes at a time)
 }
 // Waves per SIMD the kernel is compiled for (__launch_bounds__: register budget 512 / this), chosen by measurement
 // for every field size (tools/sweep_waves.sh, one box, 4x10^6 simulations, profiles/r3_sweep_waves.txt): e.g. N = 10
@@ -151,10 +151,11 @@ struct RegGeo {
     static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
     static constexpr uint32_t oHist = oLut + 128;                 // u32[N x N]
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
-    static constexpr uint32_t oW = oGrid + N * N * 8;             // [kWordRows][B] u32
+    static constexpr uint32_t oW = oGrid + (uint32_t)align16((size_t)N * N * 8);   // [kWordRows][B] u32, 16-byte aligned (odd N: padded)
     static constexpr uint32_t oLast = oW + (uint32_t)kWordRows * B * 4;      // [N][B] f64
     static constexpr uint32_t kBytes = oLast + (uint32_t)N * B * 8;
     static_assert(oW == shared_lds_bytes_reg(N) && oLast % 8 == 0, "LDS map");
+    static_assert(oW % 16 == 0, "the event handler parks fields with 16-byte LDS accesses (ds_write_b128 / ds_read_b128)");
     static_assert(kBytes == per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N), "LDS map");
     static_assert(kBytes + kLdsReserve <= kLdsPerCu, "block does not fit LDS");
     static_assert(oLast < 65536, "row bases must fit the DS immediate offset");

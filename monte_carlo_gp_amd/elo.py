@@ -104,7 +104,14 @@ class F1EloSystem:
         update_race_ratings calls of a season (:45-122) with the K of set_recency_weight (:13-38) per event, one
         kernel launch.  self.ratings is updated in place (drivers appear in it from their first event on, like in
         the reference); with snapshots=True also returns the ratings after every event.  Needs the HIP library
-        and a GPU: there is no host fallback behind this method (the per-event methods above ARE the host path)."""
+        and a GPU: there is no host fallback behind this method (the per-event methods above ARE the host path).
+
+        Limits the per-event methods do not have (mcgp_elo_season returns MCGP_E_BAD_ARG -> McgpError): at most 32
+        distinct drivers over the whole sequence (the device keeps the ratings of a 32-car field in LDS), and no
+        driver listed twice in one event -- the reference accepts that (its deltas dict keeps the last entry,
+        :62-83); feed such an event through update_quali_ratings / update_race_ratings instead.  The CLI's season
+        fixtures use the per-event host path (cli.season_fixtures); this method is the device chain ratings -> grid
+        matrix (mcgp_run_from_ratings) -> race kernel."""
         import ctypes as C
         from . import _native as N
         drivers = list(self.ratings)
