@@ -45,6 +45,7 @@ enum {
  * (run_monte_carlo argument `track_condition`, reference src/simulation.py:68) */
 enum { MCGP_SOFT = 0, MCGP_MEDIUM = 1, MCGP_HARD = 2, MCGP_INTERMEDIATE = 3, MCGP_WET = 4 };
 enum { MCGP_DRY = 0, MCGP_DAMP = 1, MCGP_WET_TRACK = 2 };
+enum { MCGP_DEVIATES_32 = 0, MCGP_DEVIATES_53 = 1 };
 
 /* RaceConfig -- replaces the dataclass at reference src/simulation.py:37-52, with
  * the dict-valued fields resolved to dense tables by the caller (the host shim):
@@ -68,6 +69,13 @@ typedef struct mcgp_config {
     int32_t comp_optimal_laps[5];
     int32_t pop_soft_hard;      /* compound id taken from {SOFT, HARD}   */
     int32_t pop_medium_hard;    /* compound id taken from {MEDIUM, HARD} */
+    /* Width of the random deviates.  0 (default): 32-bit uniforms w / 2^32 and normals from a binary32 cubic table --
+     * the product's fast path.  MCGP_DEVIATES_53: the reference's width -- 53-bit uniforms (random.random(),
+     * np.random.choice: genrand_res53) and binary64 normals (reference src/simulation.py:137,194,302,330,524) --, every
+     * draw keeping the 32-bit mode's word as its leading bits and taking 21 more from a companion Philox block; a
+     * priced option (about twice the Philox work, a binary64 inverse normal), built for field sizes 10, 20 and 21,
+     * MCGP_E_BAD_ARG for the others; mcgp_run / mcgp_run_device / mcgp_simulate_race only. */
+    int32_t deviates;
 } mcgp_config;
 
 /* Per-driver inputs as structure-of-arrays of length n; index = position of the driver

@@ -36,6 +36,7 @@ class McgpConfig(C.Structure):
         ('comp_pace_delta', C.c_double * 5), ('comp_deg_rate', C.c_double * 5),
         ('comp_optimal_laps', C.c_int32 * 5),
         ('pop_soft_hard', C.c_int32), ('pop_medium_hard', C.c_int32),
+        ('deviates', C.c_int32),          # 0: 32-bit deviates (default), 1: the reference's 53-bit / binary64 deviates
     ]
 
 

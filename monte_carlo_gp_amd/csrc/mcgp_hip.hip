@@ -13,6 +13,7 @@
 #define MCGP_FE_FN __host__ __device__ static inline
 #include "frontend_exp.h"
 #include "elo_update.h"
+#include "normal53_table.h"
 
 #include <hip/hip_runtime.h>
 
@@ -53,6 +54,16 @@ int fail(int code, const std::string &msg)
 #else
 #define MCGP_REG_SIZES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) \
     X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#endif
+
+// Field sizes the reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53) is compiled for: those of the golden
+// workloads.  Keep in step with reg_inst.hip.
+#if defined(MCGP_ONLY_N20)
+#define MCGP_WIDE_SIZES(X) X(20)
+#elif defined(MCGP_ONLY_N)
+#define MCGP_WIDE_SIZES(X)
+#else
+#define MCGP_WIDE_SIZES(X) X(10) X(20) X(21)
 #endif
 
 // Grid-probability front end (reference src/elo.py:124-141, src/predictor.py:321-407): one thread per driver row.
@@ -147,6 +158,7 @@ struct DeviceCtx {
     double *d_fe_in = nullptr;                // front end: 4 x 32 doubles in, 32 penalties, n x n matrix out
     int32_t *d_fe_pen = nullptr;
     double *d_fe_out = nullptr;
+    double *d_norm53 = nullptr;               // binary64 inverse-normal table of the reference-width build (50 KB)
     uint8_t *d_orders = nullptr;              // staging for mcgp_run(orders_out), grown on demand, kept
     size_t d_orders_bytes = 0;
     // timing events per stream (most recent call on that stream), so that calls on different streams of one
@@ -212,6 +224,8 @@ void release_ctx(DeviceCtx &c)
     c.d_fe_in = c.d_fe_out = nullptr;
     c.d_fe_pen = nullptr;
     if (c.d_orders) (void)hipFree(c.d_orders);
+    if (c.d_norm53) (void)hipFree(c.d_norm53);
+    c.d_norm53 = nullptr;
     if (c.d_elo) (void)hipFree(c.d_elo);
     c.d_elo = nullptr;
     c.elo_bytes = 0;
@@ -251,6 +265,8 @@ int init_ctx_body(int device, DeviceCtx &c)
     HIP_TRY(hipMalloc(&c.d_fe_in, sizeof(double) * 4 * MCGP_MAX_CARS));
     HIP_TRY(hipMalloc(&c.d_fe_pen, sizeof(int32_t) * MCGP_MAX_CARS));
     HIP_TRY(hipMalloc(&c.d_fe_out, sizeof(double) * MCGP_MAX_CARS * MCGP_MAX_CARS));
+    HIP_TRY(hipMalloc(&c.d_norm53, sizeof(mcgp_normal53_table_bits)));
+    HIP_TRY(hipMemcpy(c.d_norm53, mcgp_normal53_table_bits, sizeof(mcgp_normal53_table_bits), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
 #define X(N_)                                                                                         \
@@ -297,6 +313,11 @@ namespace mcgp {
                                                                   uint32_t *, uint32_t *);
 MCGP_REG_SIZES(X)
 #undef X
+#define X(N_) extern template __global__ void race_kernel_reg_wide<N_>(const KParams *, uint64_t, uint64_t, uint32_t, uint32_t, \
+                                                                       unsigned long long *, uint8_t *, const uint8_t *, uint32_t, \
+                                                                       uint32_t *, uint32_t *, const double *);
+MCGP_WIDE_SIZES(X)
+#undef X
 #define X(N_) extern template __global__ void race_kernel_reg_batch<N_>(const KParams *, const BatchItem *, uint32_t, uint64_t, \
                                                                         unsigned long long *, uint32_t, uint32_t *, uint32_t *);
 MCGP_REG_SIZES(X)
@@ -307,6 +328,18 @@ namespace {
 
 using BatchKernelFn = void (*)(const mcgp::KParams *, const mcgp::BatchItem *, uint32_t, uint64_t, unsigned long long *,
                                uint32_t, uint32_t *, uint32_t *);
+using WideKernelFn = void (*)(const mcgp::KParams *, uint64_t, uint64_t, uint32_t, uint32_t, unsigned long long *,
+                              uint8_t *, const uint8_t *, uint32_t, uint32_t *, uint32_t *, const double *);
+WideKernelFn select_wide_kernel(uint32_t n)
+{
+    switch (n) {
+#define X(N_) case N_: return &mcgp::race_kernel_reg_wide<N_>;
+        MCGP_WIDE_SIZES(X)
+#undef X
+        default: return nullptr;
+    }
+}
+
 BatchKernelFn select_batch_kernel(uint32_t n)
 {
     switch (n) {
@@ -412,7 +445,19 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
 {
     if (n_sims == 0) return MCGP_OK;
     bool is_reg = false;
-    const KernelFn kernel = select_kernel(kp, &is_reg);
+    KernelFn kernel = select_kernel(kp, &is_reg);
+    // the reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): the register kernel's geometry, its own code
+    WideKernelFn wide = nullptr;
+    if (kp.wide) {
+        wide = select_wide_kernel((uint32_t)kp.n);
+        if (!wide || !mcgp::reg_kernel_serves(kp))
+            return fail(MCGP_E_BAD_ARG, "deviates = MCGP_DEVIATES_53 is built for fields of 10, 20 and 21 cars (and problems "
+                                        "the register kernel takes)");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)c.lds_per_block));
+        is_reg = true;
+        kernel = nullptr;
+    }
     DeviceCtx::Slot *sl = nullptr;
     if (!fe.on)           // a block whose matrix is written by the device front end is never shared
         for (auto &cand : c.slot)
@@ -485,7 +530,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     uint32_t grid = 0, block = 0, lds = 0;
     for (uint64_t done = 0; done < n_sims; done += cap) {
         const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
-        launch_geometry(c, (uint32_t)kp.n, is_reg, kernel, m, &grid, &block, &lds);
+        launch_geometry(c, (uint32_t)kp.n, is_reg, wide ? reinterpret_cast<KernelFn>(wide) : kernel, m, &grid, &block, &lds);
         // units of work: the register kernel's waves claim chunks of 64 simulations from the stream's counter, a block
         // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
         const uint64_t unit = is_reg ? 64u : block;
@@ -507,10 +552,16 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
                 c.timer[ti].retire_bytes = want;
             }
         }
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
-                           (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
-                           d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
-                           (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire);
+        if (wide)
+            hipLaunchKernelGGL(wide, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
+                               d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
+                               (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire, c.d_norm53);
+        else
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
+                               d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
+                               (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c.timer[ti].stop, stream));
@@ -543,7 +594,8 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     c.last_grid = grid;
     c.last_block = block;
     c.last_lds = lds;
-    if (is_reg) std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel_reg<%d>", kp.n);
+    if (wide) std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel_reg_wide<%d>", kp.n);
+    else if (is_reg) std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel_reg<%d>", kp.n);
     else std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel");
     return MCGP_OK;
 }
@@ -864,6 +916,7 @@ int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_
         if (rc != MCGP_OK) return rc;
         // the batch kernel is the register kernel; a problem only the generic kernel takes (lap times near zero, values
         // near the ends of binary64) is refused rather than silently run elsewhere: use mcgp_run for it
+        if (kps[p].wide) return fail(MCGP_E_BAD_ARG, "deviates = MCGP_DEVIATES_53 is not available in a batch: use mcgp_run");
         if (!mcgp::reg_kernel_serves(kps[p]))
             return fail(MCGP_E_BAD_ARG, "a problem of the batch is outside the register kernel's domain (see reg_kernel_serves): run it with mcgp_run");
         items[p].sim_offset = sim_offsets ? sim_offsets[p] : 0ull;

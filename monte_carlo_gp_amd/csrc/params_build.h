@@ -20,6 +20,22 @@ inline uint64_t threshold(double p)
     return (uint64_t)std::ceil(x);
 }
 
+// u < p for the 53-bit uniform u = q / 2^53  <=>  q < ceil(p * 2^53)
+inline uint64_t threshold53(double p)
+{
+    if (!(p > 0.0)) return 0;
+    const double x = p * 9007199254740992.0;
+    if (x >= 9007199254740992.0) return 9007199254740992ull;
+    return (uint64_t)std::ceil(x);
+}
+// survival factor of the 64-bit retirement chain: 2^64 - ceil(p 2^64); 0 for p >= 1 (and for p <= 0, where the chain is
+// not used: t_dnf = 0 says "never")
+inline uint64_t survival64(double p)
+{
+    if (!(p > 0.0) || p >= 1.0) return 0;
+    return (uint64_t)0 - (uint64_t)std::ceil(p * 18446744073709551616.0);      // p 2^64 <= 2^64 - 2^11: fits
+}
+
 // Returns MCGP_OK or MCGP_E_BAD_ARG with *err set to a static message.
 inline int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const double *grid_probs, uint32_t n,
                         KParams *kp, const char **err)
@@ -53,6 +69,13 @@ inline int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const d
     kp->t_sc = threshold(cfg->sc_probability);
     kp->t_vsc = threshold(cfg->vsc_probability);
     kp->t_vsc_tire = threshold(0.3);                                   // reference :392
+    if (cfg->deviates != MCGP_DEVIATES_32 && cfg->deviates != MCGP_DEVIATES_53)
+        { *err = "deviates must be MCGP_DEVIATES_32 or MCGP_DEVIATES_53"; return MCGP_E_BAD_ARG; }
+    kp->wide = cfg->deviates == MCGP_DEVIATES_53;
+    kp->t53_red = threshold53(cfg->red_flag_probability);
+    kp->t53_sc = threshold53(cfg->sc_probability);
+    kp->t53_vsc = threshold53(cfg->vsc_probability);
+    kp->t53_vsc_tire = threshold53(0.3);
     for (int c = 0; c < 5; ++c) {
         kp->comp_deg[c] = cfg->comp_deg_rate[c];
         kp->comp_delta[c] = cfg->comp_pace_delta[c];
@@ -67,6 +90,8 @@ inline int build_params(const mcgp_config *cfg, const mcgp_drivers *drv, const d
         kp->variance[d] = drv->variance[d];
         kp->t_dnf1[d] = threshold(drv->team_dnf[d] * 4.0);             // reference :282,286-287
         kp->t_dnf[d] = threshold(drv->lap_dnf[d]);
+        kp->t53_dnf1[d] = threshold53(drv->team_dnf[d] * 4.0);
+        kp->q64_dnf[d] = survival64(drv->lap_dnf[d]);
         const double pit_deg = drv->tire_deg_pit[d];
         for (int c = 0; c < 5; ++c) {
             int opt = cfg->comp_optimal_laps[c];                       // reference :455-462

@@ -68,6 +68,13 @@ struct KParams {
     uint16_t opt_laps[kMaxCars * kCompStride];   // pit threshold per driver and compound  :454-462
     double grid_probs[kMaxCars * kMaxCars];      // [driver][slot], row stride n
     uint32_t normal_bits[kNormalRows * 4];
+    // ---- reference-width deviates (mcgp_config.deviates = MCGP_DEVIATES_53; race_kernel_reg<N, true>) ----
+    int32_t wide, pad1;
+    // u < p for the 53-bit uniform u = q / 2^53  <=>  q < ceil(p 2^53)   (p 2^53 is exact in binary64)
+    uint64_t t53_red, t53_sc, t53_vsc, t53_vsc_tire;
+    uint64_t t53_dnf1[kMaxCars];
+    // retirement chain of laps >= 2 in 64 bits: q = 2^64 - ceil(p 2^64) (0 for p >= 1; unused for p <= 0: t_dnf = 0)
+    uint64_t q64_dnf[kMaxCars];
 };
 
 // LDS bytes: block-shared tables, then per-thread rows.
@@ -122,6 +129,39 @@ __device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
     z = __builtin_fmaf(z, t, c.x);
     return (w >> 31) ? -z : z;
 }
+
+// Reference-width normal: z0 = Phi^-1((q + 0.5) / 2^53) < 0 for the 52-bit tail index q, degree-7 polynomial on
+// log-spaced cells, explicit binary64 fma (tools/gen_normal53_table.py; the oracle's normal53_tail is the same text).
+// `tab` = the table's rows of 8 doubles in device memory.
+__device__ __forceinline__ double normal53_tail(uint64_t q, const double *__restrict__ tab)
+{
+    const bool small = q < 16ull;
+    const uint64_t qq = small ? 16ull : q;
+    const int sh = 59 - __clzll((long long)qq);                  // floor(log2 qq) - 4
+    const uint32_t k = (uint32_t)(qq >> sh) & 15u;
+    const uint64_t r = qq & ((1ull << sh) - 1ull);
+    const double t = small ? 0.0 : ((double)r + 0.5) * __hiloint2double((1023 - sh) << 20, 0);   // x 2^-sh, exact
+    const uint32_t row = small ? (uint32_t)q : 16u + 16u * (uint32_t)sh + k;
+    const double *c = tab + 8u * row;
+    double z = c[7];
+#pragma unroll
+    for (int d = 6; d >= 0; --d) z = __builtin_fma(z, t, c[d]);
+    return z;
+}
+// the draw's 52-bit tail index and the deviate: sign and the 31 magnitude bits from the word w the 32-bit mode reads,
+// 21 more bits from the same word position of the companion block
+__device__ __forceinline__ double normal53(uint32_t w, uint32_t companion, const double *__restrict__ tab)
+{
+    const uint64_t q = ((uint64_t)(w & 0x7fffffffu) << 21) | (uint64_t)(companion >> 11);
+    const double z0 = normal53_tail(q, tab);
+    return (w >> 31) ? -z0 : z0;
+}
+// the 53-bit uniform's numerator q (u = q / 2^53) of a draw
+__device__ __forceinline__ uint64_t uniform53(uint32_t w, uint32_t companion)
+{
+    return ((uint64_t)w << 21) | (uint64_t)(companion >> 11);
+}
+constexpr uint32_t kCompanion = 0x8000u;         // counter word 3 of a draw's companion block: | kCompanion
 
 __device__ __forceinline__ float normal_from_u32(uint32_t w, const float4 *__restrict__ tab)
 {

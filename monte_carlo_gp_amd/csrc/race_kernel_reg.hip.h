@@ -470,6 +470,9 @@ __host__ __device__ inline double reg_time_floor(const KParams &kp)
 // race_common.hip.h), where a probability >= 1 is just a survival threshold of 0.
 __host__ __device__ inline bool reg_kernel_serves(const KParams &kp)
 {
+    // an overtake attempt is told from its threshold being non-zero when a lane has more than eight of them in a pass,
+    // which wants overtake_delta >= 0 (dl > delta >= 0 makes ceil(dl 2^31) >= 1)
+    if (!(kp.overtake_delta >= 0.0)) return false;
     // The kernel's tables carry powers of two (pace x 2^31, degradation x 2^-16 or x 2^15): exact, a power of two
     // commutes with every rounding, unless the scaled value leaves the normal range.  Magnitudes no race has, but the
     // kernel is bit-exact on what it accepts: anything near the ends of binary64 goes to the generic kernel.
@@ -560,13 +563,19 @@ constexpr uint32_t kTicketChunks = 0xFFFFFFFFu;      // reg_simulate: "claim chu
 // evenly (tools/valu_peak.hip: with a fixed share per wave, 3 waves per SIMD ran 14 % slower), and it evens out blocks,
 // CUs and the tail of the launch as well.  Which wave runs a simulation changes nothing in its result: every draw is
 // addressed by the simulation's global id.
-template <int N>
+// WIDE = the reference's deviate width (mcgp_config.deviates = MCGP_DEVIATES_53): every draw keeps the word the default
+// mode reads as its leading 32 bits and takes 21 more from the same word position of a companion Philox block (counter
+// word 3 | kCompanion); Bernoulli tests compare 53-bit numerators with 53-bit thresholds, normals are binary64
+// (normal53, race_common.hip.h; `norm53` = its table in device memory).  The oracle's PHILOX53 back-end is the same
+// arithmetic.  A priced option: everything WIDE sits behind `if constexpr`, the default kernel is untouched by it.
+template <int N, bool WIDE = false>
 __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid,
                                              uint32_t *__restrict__ ticket, uint64_t n_sims,
                                              uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
                                              uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid,
                                              uint32_t n_chunks, uint32_t *__restrict__ retire_ws_base, uint32_t ws_stride,
-                                             uint32_t ws_first_lane, uint32_t fixed_chunk = kTicketChunks)
+                                             uint32_t ws_first_lane, uint32_t fixed_chunk = kTicketChunks,
+                                             const double *__restrict__ norm53 = nullptr)
 {
     using G = RegGeo<N>;
     constexpr int B = G::B;
@@ -639,7 +648,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         {
             uint32_t remaining = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
             int n_remaining = N;
-            uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+            uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
 #pragma unroll 1
             for (int pos = 0; pos < N; ++pos) {
                 uint32_t sel;
@@ -649,10 +658,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     sel = (uint32_t)((pos * 7 + (int)(c0 & 3u)) % N);
                     while (!((remaining >> sel) & 1u)) sel = (sel + 1u) % (uint32_t)N;
                 } else {
-                    if ((pos & 3) == 0)
+                    if ((pos & 3) == 0) {
                         philox4x32_10(c0, c1, 0u, kPurposeGrid | (uint32_t)(pos >> 2), seed_lo, seed_hi, g0, g1, g2, g3);
+                        if constexpr (WIDE)
+                            philox4x32_10(c0, c1, 0u, kPurposeGrid | kCompanion | (uint32_t)(pos >> 2), seed_lo, seed_hi, h0, h1, h2, h3);
+                    }
                     const uint32_t gw = (pos & 3) == 0 ? g0 : (pos & 3) == 1 ? g1 : (pos & 3) == 2 ? g2 : g3;
-                    const double u = u32_to_unit(gw);
+                    const uint32_t hw = (pos & 3) == 0 ? h0 : (pos & 3) == 1 ? h1 : (pos & 3) == 2 ? h2 : h3;
+                    const double u = WIDE ? (double)uniform53(gw, hw) * 0x1p-53 : u32_to_unit(gw);
                     const uint32_t gcol = G::oGrid + (uint32_t)(pos * N) * 8u;           // [slot][driver], wave-uniform
                     // Fast path, no division.  The reference normalises the column over the remaining drivers (:119-126),
                     // numpy's choice() normalises the cumulative sums once more and takes the first entry above u: the
@@ -738,47 +751,98 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
         }
 
         // ================= _simulate_lap_1, reference :275-311 =================
-        // draws by DRIVER (wave-uniform thresholds), staged in the LAST rows, which lap 1 does not use otherwise (Q3):
-        // low word = lap-noise deviate or NaN (retired), high word = start deviate
+        if constexpr (WIDE) {
+            // reference-width deviates: two passes over the drivers, each staging one binary64 deviate per driver in the
+            // LAST rows -- first the lap noise (NaN = retired on lap 1), then the start delta
 #pragma unroll 1
-        for (int d = 0; d < N; ++d) {
-            uint32_t w0, w1, w2, w3;
-            philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
-            const bool out = (uint64_t)w0 < P->t_dnf1[d];
-            lds_st<float>(l_row(d), out ? kNaN : normal_from_u32_rows(w1, norm_row));
-            lds_st<float>(l_row(d) + 4u, normal_from_u32_rows(w2, norm_row));
-        }
+            for (int d = 0; d < N; ++d) {
+                uint32_t w0, w1, w2, w3, x0, x1, x2, x3;
+                philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
+                philox4x32_10(c0, c1, 1u, kPurposeCar | kCompanion | (uint32_t)d, seed_lo, seed_hi, x0, x1, x2, x3);
+                const bool out = uniform53(w0, x0) < P->t53_dnf1[d];
+                lds_st<double>(l_row(d), out ? __builtin_nan("") : normal53(w1, x1, norm53));
+            }
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const uint32_t p = pk[i];
-            const uint32_t la = last_of(p);
-            const float z = lds_ld<float>(G::oLast + la);
-            const double zs = (double)lds_ld<float>(G::oLast + la + 4u);
-            const uint32_t id16 = (p >> 6) & 0x1F0u;
-            const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);                        // {variance, base pace}
-            const double eff = lds_ld<double>(G::oIc + id16 + ((p & k3CompMask) << 2));
-            const double cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));
-            if (z != z) {
-                pk[i] = (p & ~k3AgeMask) | k3Dnf | (1u << k3AgeShift);
-                // The reference leaves a lap-1 retirement at cumulative_time 0.0, so several of them tie; ties sort
-                // in grid order.  Here the car on grid slot i is given -(i + 1) * 2^-1000 instead: still below every
-                // running car's time, never equal to anything, and among themselves in the order the only consumer
-                // of their relative order wants -- the classification sorts retirements of one lap by time
-                // DESCENDING, i.e. grid slot ascending, exactly the reference's stable tie.  (Overtakes, events and
-                // _update_positions skip retired cars; nothing else reads these values.)  Keeping them apart lets
-                // "strictly increasing times" be the sortedness test of the hot loop.
-                cum[i] = -(double)(i + 1) * 0x1p-1000;
-            } else {
-                const double tire = (double)(p & k3AgeMask) * eff;                          // (eff x 2^-16)
-                const double fuel_effect = (110.0 - 110.0) * 0.03;
-                const double noise = 0.0 + vb.x * (double)z;
-                const double base_lap = vb.y + tire - fuel_effect + cdelta - 0.0 + noise;
-                double pf = 0.5 + (double)(i + 1) * 0.1;
-                if (!(pf < 1.5)) pf = 1.5;
-                double sd = 0.0 + pf * zs;
-                if (i + 1 <= 3 && 1.0 < sd) sd = 1.0;
-                cum[i] = 0.0 + (base_lap - sd * 0.5);
-                pk[i] = p + (1u << k3AgeShift);
+            for (int i = 0; i < N; ++i) {
+                const uint32_t p = pk[i];
+                const double z = lds_ld<double>(G::oLast + last_of(p));
+                const uint32_t id16 = (p >> 6) & 0x1F0u;
+                const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);                        // {variance, base pace}
+                const double eff = lds_ld<double>(G::oIc + id16 + ((p & k3CompMask) << 2));
+                const double cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));
+                if (z != z) {
+                    pk[i] = (p & ~k3AgeMask) | k3Dnf | (1u << k3AgeShift);
+                    cum[i] = -(double)(i + 1) * 0x1p-1000;                              // (see the default path below)
+                } else {
+                    const double tire = (double)(p & k3AgeMask) * eff;
+                    const double fuel_effect = (110.0 - 110.0) * 0.03;
+                    const double noise = 0.0 + vb.x * z;
+                    cum[i] = vb.y + tire - fuel_effect + cdelta - 0.0 + noise;          // base_lap, finished below
+                }
+            }
+#pragma unroll 1
+            for (int d = 0; d < N; ++d) {
+                uint32_t w0, w1, w2, w3, x0, x1, x2, x3;
+                philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
+                philox4x32_10(c0, c1, 1u, kPurposeCar | kCompanion | (uint32_t)d, seed_lo, seed_hi, x0, x1, x2, x3);
+                lds_st<double>(l_row(d), normal53(w2, x2, norm53));
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const uint32_t p = pk[i];
+                const double zs = lds_ld<double>(G::oLast + last_of(p));
+                if (!(p & k3Dnf)) {
+                    double pf = 0.5 + (double)(i + 1) * 0.1;
+                    if (!(pf < 1.5)) pf = 1.5;
+                    double sd = 0.0 + pf * zs;
+                    if (i + 1 <= 3 && 1.0 < sd) sd = 1.0;
+                    cum[i] = 0.0 + (cum[i] - sd * 0.5);
+                    pk[i] = p + (1u << k3AgeShift);
+                }
+            }
+        } else {
+            // draws by DRIVER (wave-uniform thresholds), staged in the LAST rows, which lap 1 does not use otherwise (Q3):
+            // low word = lap-noise deviate or NaN (retired), high word = start deviate
+#pragma unroll 1
+            for (int d = 0; d < N; ++d) {
+                uint32_t w0, w1, w2, w3;
+                philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
+                const bool out = (uint64_t)w0 < P->t_dnf1[d];
+                lds_st<float>(l_row(d), out ? kNaN : normal_from_u32_rows(w1, norm_row));
+                lds_st<float>(l_row(d) + 4u, normal_from_u32_rows(w2, norm_row));
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const uint32_t p = pk[i];
+                const uint32_t la = last_of(p);
+                const float z = lds_ld<float>(G::oLast + la);
+                const double zs = (double)lds_ld<float>(G::oLast + la + 4u);
+                const uint32_t id16 = (p >> 6) & 0x1F0u;
+                const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);                        // {variance, base pace}
+                const double eff = lds_ld<double>(G::oIc + id16 + ((p & k3CompMask) << 2));
+                const double cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));
+                if (z != z) {
+                    pk[i] = (p & ~k3AgeMask) | k3Dnf | (1u << k3AgeShift);
+                    // The reference leaves a lap-1 retirement at cumulative_time 0.0, so several of them tie; ties sort
+                    // in grid order.  Here the car on grid slot i is given -(i + 1) * 2^-1000 instead: still below every
+                    // running car's time, never equal to anything, and among themselves in the order the only consumer
+                    // of their relative order wants -- the classification sorts retirements of one lap by time
+                    // DESCENDING, i.e. grid slot ascending, exactly the reference's stable tie.  (Overtakes, events and
+                    // _update_positions skip retired cars; nothing else reads these values.)  Keeping them apart lets
+                    // "strictly increasing times" be the sortedness test of the hot loop.
+                    cum[i] = -(double)(i + 1) * 0x1p-1000;
+                } else {
+                    const double tire = (double)(p & k3AgeMask) * eff;                          // (eff x 2^-16)
+                    const double fuel_effect = (110.0 - 110.0) * 0.03;
+                    const double noise = 0.0 + vb.x * (double)z;
+                    const double base_lap = vb.y + tire - fuel_effect + cdelta - 0.0 + noise;
+                    double pf = 0.5 + (double)(i + 1) * 0.1;
+                    if (!(pf < 1.5)) pf = 1.5;
+                    double sd = 0.0 + pf * zs;
+                    if (i + 1 <= 3 && 1.0 < sd) sd = 1.0;
+                    cum[i] = 0.0 + (base_lap - sd * 0.5);
+                    pk[i] = p + (1u << k3AgeShift);
+                }
             }
         }
 #pragma unroll 1
@@ -828,7 +892,30 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             for (int d0 = 0; d0 < N; d0 += 4) {
                 uint32_t rw[4];
                 philox4x32_10(c0, c1, 0u, kPurposeRetire | (uint32_t)(d0 >> 2), seed_lo, seed_hi, rw[0], rw[1], rw[2], rw[3]);
-                uint32_t q[4], S[4], survived[4];
+                uint32_t survived[4];
+                if constexpr (WIDE) {
+                    // the word refined to 53 bits (left-aligned in 64) against 64-bit thresholds S_2 = q,
+                    // S_{k+1} = floor(S_k q / 2^64), q = 2^64 - ceil(p 2^64) (P->q64_dnf; the oracle's philox_retirement_lap)
+                    uint32_t rx[4];
+                    philox4x32_10(c0, c1, 0u, kPurposeRetire | kCompanion | (uint32_t)(d0 >> 2), seed_lo, seed_hi, rx[0], rx[1], rx[2], rx[3]);
+                    uint64_t Q[4], q64[4], S64[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Q[j] = ((uint64_t)rw[j] << 32) | ((uint64_t)(rx[j] >> 11) << 11);
+                        q64[j] = d0 + j < N ? P->q64_dnf[d0 + j] : 0ull;
+                        S64[j] = q64[j];
+                        survived[j] = 0u;
+                    }
+#pragma unroll 1
+                    for (int k = 2; k <= L; ++k) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            survived[j] += Q[j] < S64[j] ? 1u : 0u;
+                            S64[j] = __umul64hi(S64[j], q64[j]);
+                        }
+                    }
+                } else {
+                uint32_t q[4], S[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint64_t t = d0 + j < N ? P->t_dnf[d0 + j] : 0ull;         // ceil(p 2^32), 0 .. 2^32
@@ -845,6 +932,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         survived[j] += rw[j] < S[j] ? 1u : 0u;                       // survives lap k
                         S[j] = retire_next_threshold(S[j], q[j]);
                     }
+                }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -890,19 +978,25 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             const KParams *Pl = P;
             pin_ptr(Pl);
             const double pit_loss = Pl->pit_loss, od31 = Pl->overtake_delta_31, dirty_thr = Pl->dirty_thr, dirty_pen = Pl->dirty_pen;
-            const uint64_t t_red = Pl->t_red, t_sc = Pl->t_sc, t_vsc = Pl->t_vsc, t_vsc_tire = Pl->t_vsc_tire;
+            const uint64_t t_red = WIDE ? Pl->t53_red : Pl->t_red, t_sc = WIDE ? Pl->t53_sc : Pl->t_sc,
+                           t_vsc = WIDE ? Pl->t53_vsc : Pl->t_vsc, t_vsc_tire = WIDE ? Pl->t53_vsc_tire : Pl->t_vsc_tire;
             // ---- race-interrupting events, :168-176 ----
             {
                 uint32_t e0, e1, e2, e3;
                 philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent, k0l, k1l, e0, e1, e2, e3);
+                uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+                if constexpr (WIDE) philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent | kCompanion, k0l, k1l, f0, f1, f2, f3);
                 if (MCGP_DUP & 16) {
                     uint32_t f0, f1, f2, f3;
                     philox4x32_10(c0l ^ e0, c1l, (uint32_t)lap, kPurposeEvent, k0l, k1l, f0, f1, f2, f3);
                     if ((f0 | f1 | f2 | f3) == 0u) e0 = f0;     // never true in practice; keeps the block alive
                 }
-                const bool red = (uint64_t)e0 < t_red;
-                const bool sc = !red && (uint64_t)e1 < t_sc;
-                const bool vsc = !red && !sc && (uint64_t)e2 < t_vsc;
+                // (the draw's numerator: the 32-bit word, or the word followed by 21 bits of its companion)
+                const uint64_t u_red = WIDE ? uniform53(e0, f0) : (uint64_t)e0, u_sc = WIDE ? uniform53(e1, f1) : (uint64_t)e1,
+                               u_vsc = WIDE ? uniform53(e2, f2) : (uint64_t)e2, u_tire = WIDE ? uniform53(e3, f3) : (uint64_t)e3;
+                const bool red = u_red < t_red;
+                const bool sc = !red && u_sc < t_sc;
+                const bool vsc = !red && !sc && u_vsc < t_vsc;
                 MCGP_STAT(12, red || sc || vsc);
 #if MCGP_COOPERATIVE_EVENTS
                 // An event is rare per simulation (2.7 % of laps on the benchmark fields) but not per wave: 83 % of
@@ -925,7 +1019,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     pin(tid_e);
                     const uint32_t lane = tid_e & 63u;
                     const uint32_t wbase = G::oW + ((tid_e * 4u) & ~255u);      // this wave's 256-byte window of row 0
-                    const bool dec_age = sc || (vsc && (uint64_t)e3 < t_vsc_tire);
+                    const bool dec_age = sc || (vsc && u_tire < t_vsc_tire);
                     const uint32_t flags = (red ? 1u : 0u) | (vsc ? 4u : 0u) | (dec_age ? 8u : 0u);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     const uint32_t red_bits = (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
@@ -1030,7 +1124,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     // leader (red flag 0.1 s apart, safety car 0.5 s apart, VSC gaps x 0.8), their time_behind_leader
                     // -- kept as the dirty-air flag -- follows, tyres age one lap less (SC; VSC with probability 0.3)
                     // or are changed (red flag).  Retired cars are left alone.
-                    const bool dec_age = sc || (vsc && (uint64_t)e3 < t_vsc_tire);
+                    const bool dec_age = sc || (vsc && u_tire < t_vsc_tire);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     const uint32_t red_bits = (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
                     const uint32_t dec_unit = dec_age ? (1u << k3AgeShift) : 0u;
@@ -1110,18 +1204,27 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j)
                         if (i0 + j < N) in[j] = load_slot(pk[i0 + j], lut_base);
-                    uint32_t w[MCGP_STEP_BATCH / 4][4];
+                    uint32_t w[MCGP_STEP_BATCH / 4][4], x[MCGP_STEP_BATCH / 4][4];
 #pragma unroll
                     for (int b = 0; b < MCGP_STEP_BATCH / 4; ++b) {
                         w[b][0] = w[b][1] = w[b][2] = w[b][3] = 0u;
-                        if (i0 + 4 * b < N)
+                        x[b][0] = x[b][1] = x[b][2] = x[b][3] = 0u;
+                        if (i0 + 4 * b < N) {
                             philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | (uint32_t)((i0 >> 2) + b), k0l, k1l,
                                           w[b][0], w[b][1], w[b][2], w[b][3]);
+                            if constexpr (WIDE)
+                                philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeCar | kCompanion | (uint32_t)((i0 >> 2) + b), k0l, k1l,
+                                              x[b][0], x[b][1], x[b][2], x[b][3]);
+                        }
                     }
-                    float z[MCGP_STEP_BATCH];
+                    // the lap-noise deviate: binary32 from the cubic table, or (WIDE) binary64 from the degree-7 table
+                    using Deviate = std::conditional_t<WIDE, double, float>;
+                    Deviate z[MCGP_STEP_BATCH];
 #pragma unroll
-                    for (int j = 0; j < MCGP_STEP_BATCH; ++j)
-                        z[j] = (i0 + j < N) ? normal_from_u32_rows(w[j >> 2][j & 3], norm_row) : 0.0f;
+                    for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
+                        if constexpr (WIDE) z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
+                        else z[j] = (i0 + j < N) ? normal_from_u32_rows(w[j >> 2][j & 3], norm_row) : 0.0f;
+                    }
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
                         const int i = i0 + j;
@@ -1175,79 +1278,15 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // succeed.  Everything is scaled by 2^31 (tables, reg_load_tables): u < min(0.5, delta / 2) for the
                 // uniform u = w 2^-32 is  w < 2^31  and  w < delta 2^31,  i.e.  w < thr = min(ceil(delta 2^31), 2^31)
                 // -- one integer per pair instead of a binary64 delta kept across the draw-word generation.
-                // ---- overtakes: draw words ----
-                // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4.  The first eight -- all that
-                // all but a few wave-passes in a thousand need -- are drawn FIRST, into the eight rows of the W plane: the
-                // stage below then fetches a pair's word the moment its row is known, and no array of addresses or of
-                // candidate bits has to live across the Philox blocks (which cost a dozen registers themselves).
-                {
-                    uint32_t o0, o1, o2, o3;
-                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass), k0l, k1l, o0, o1, o2, o3);
-                    lds_st<uint32_t>(w_row(0), o0);
-                    lds_st<uint32_t>(w_row(1), o1);
-                    lds_st<uint32_t>(w_row(2), o2);
-                    lds_st<uint32_t>(w_row(3), o3);
-                    philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 1), k0l, k1l, o0, o1, o2, o3);
-                    lds_st<uint32_t>(w_row(4), o0);
-                    lds_st<uint32_t>(w_row(5), o1);
-                    lds_st<uint32_t>(w_row(6), o2);
-                    lds_st<uint32_t>(w_row(7), o3);
-                }
                 uint32_t thr[N];
                 uint32_t ow[N];                  // ow[i] = the draw word of the attempt at pair i
-                // W-plane address of the NEXT attempt's word: a running sum over the candidates so far (row k of the plane
-                // holds the word of the lane's k-th attempt), advanced inside ovt_threshold by the compare that makes
-                // the pair a candidate
-                uint32_t row = tid4;
-                {
-                    constexpr int H = MCGP_PACE_BATCH;
-                    const uint32_t row_stride = (uint32_t)(B * 4);
-                    double pace_prev = 0.0;
-#pragma unroll
-                    for (int h = 0; h < N; h += H) {
-                        MCGP_SCHED_FENCE();
-                        double pb[H], pd[H], pa[H];
-#pragma unroll
-                        for (int j = 0; j < H; ++j) {
-                            if (h + j < N) {
-                                const uint32_t id16 = (pk[h + j] >> 6) & 0x3F0u;      // 16 x (32 dnf + driver)
-                                const f64x2 bd = lds_ld_f64x2(G::oDrvB + id16);
-                                pb[j] = bd.x;
-                                pd[j] = bd.y;
-                                pa[j] = lds_ld<double>(G::oDrsB + (pk[h + j] & k3Drs));
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < H; ++j) {
-                            const int i = h + j;
-                            if (i < N) {
-                                // a retired car's pace is NaN (table): its two pairs compare false below (:511)
-                                const double pace = pb[j] + (double)(pk[i] & k3AgeMask) * pd[j];
-                                if (i > 0) {
-                                    const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520 (x 2^31)
-                                    // candidate iff dl > overtake_delta (:522); threshold min(ceil(dl), 2^31) (:523-524)
-                                    uint32_t next;
-                                    ovt_threshold(dl, od31, row, row_stride, thr[i], next);
-                                    // (a pair that is no candidate fetches the word of the next attempt, or one just past
-                                    //  the plane: its threshold is 0)
-                                    ow[i] = lds_ld<uint32_t>(G::oW + row);
-                                    row = next;
-                                }
-                                pace_prev = pace;
-                            }
-                        }
-                    }
-                    thr[0] = 0u;
-                    ow[0] = 0u;
-                }
-                const uint32_t words_end = row - tid4;          // = attempts of this lane x the row stride
-                MCGP_STAT(0 + pass, words_end != 0u);
-                if (words_end == 0u) break;
-                // A wave with a lane that has more than eight attempts takes the general path, 8 attempts at a time, and
-                // leaves its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
-                if (__builtin_expect(MCGP_ANY(words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
-                    // the candidate mask, worked out again from the pace deltas (a threshold of 0 does not tell "no attempt"
-                    // from "an attempt that cannot succeed", which a negative overtake_delta allows)
+                uint32_t hits53 = 0u;            // (WIDE) bit i: the attempt at pair i succeeds
+                uint32_t n_attempts = 0u;        // (statistics of the host build)
+                if constexpr (WIDE) {
+                    // Reference-width draws: u < min(0.5, delta / 2) for u = q / 2^53 is q < min(ceil(delta 2^52), 2^52); the
+                    // pace deltas carry 2^31, so the threshold is min(ceil(dl 2^21), 2^52).  Plain code, four attempts at
+                    // a time: their words in rows 0..3 of the W plane, the companion words in rows 4..7.
+                    uint64_t thr64[N];
                     uint32_t cand = 0u;
                     {
                         double pace_prev = 0.0;
@@ -1255,44 +1294,160 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         for (int i = 0; i < N; ++i) {
                             const f64x2 bd = lds_ld_f64x2(G::oDrvB + ((pk[i] >> 6) & 0x3F0u));
                             const double pace = bd.x + (double)(pk[i] & k3AgeMask) * bd.y;
+                            thr64[i] = 0ull;
                             if (i > 0) {
                                 const double dl = (pace_prev - pace) + lds_ld<double>(G::oDrsB + (pk[i] & k3Drs));
-                                cand |= dl > od31 ? (1u << i) : 0u;
+                                const bool c = dl > od31;                                           // :522 (NaN: retired)
+                                double x = ceil_f64(dl * 0x1p21);
+                                x = x < 0x1p52 ? x : 0x1p52;
+                                const uint32_t xh = c ? cvt_u32_f64_sat(x * 0x1p-32) : 0u;
+                                const uint32_t xl = c ? cvt_u32_f64_sat(x - (double)xh * 0x1p32) : 0u;
+                                thr64[i] = ((uint64_t)xh << 32) | (uint64_t)xl;
+                                cand |= c ? (1u << i) : 0u;
                             }
                             pace_prev = pace;
                         }
                     }
-                    uint32_t hits = 0u, rest = cand;
+                    MCGP_STAT(0 + pass, cand != 0u);
+                    if (cand == 0u) break;
+                    uint32_t rest = cand;
 #pragma unroll 1
-                    for (int chunk = 0; rest != 0u; ++chunk) {
-                        uint32_t m = rest;                                  // `rest` without its 8 lowest set bits
+                    for (int chunk = 0; MCGP_ANY(rest != 0u); ++chunk) {
+                        uint32_t m = rest;                                  // `rest` without its 4 lowest set bits
 #pragma unroll 1
-                        for (int k = 0; k < kWordRows && m != 0u; ++k) m &= m - 1u;
-                        const uint32_t cur = rest & ~m;                     // attempts 8 chunk .. 8 chunk + 7
-#pragma unroll 1
-                        for (int b = 0; b < 2; ++b) {
-                            uint32_t o0, o1, o2, o3;
-                            philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 2 * chunk + b), k0l,
-                                          k1l, o0, o1, o2, o3);
-                            lds_st<uint32_t>(w_row(4 * b + 0), o0);
-                            lds_st<uint32_t>(w_row(4 * b + 1), o1);
-                            lds_st<uint32_t>(w_row(4 * b + 2), o2);
-                            lds_st<uint32_t>(w_row(4 * b + 3), o3);
-                        }
+                        for (int k = 0; k < 4 && m != 0u; ++k) m &= m - 1u;
+                        const uint32_t cur = rest & ~m;                     // attempts 4 chunk .. 4 chunk + 3
+                        uint32_t o0, o1, o2, o3;
+                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + chunk), k0l, k1l, o0, o1, o2, o3);
+                        lds_st<uint32_t>(w_row(0), o0);
+                        lds_st<uint32_t>(w_row(1), o1);
+                        lds_st<uint32_t>(w_row(2), o2);
+                        lds_st<uint32_t>(w_row(3), o3);
+                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | kCompanion | (uint32_t)(8 * pass + chunk), k0l, k1l, o0, o1, o2, o3);
+                        lds_st<uint32_t>(w_row(4), o0);
+                        lds_st<uint32_t>(w_row(5), o1);
+                        lds_st<uint32_t>(w_row(6), o2);
+                        lds_st<uint32_t>(w_row(7), o3);
                         uint32_t h = 0u;
 #pragma unroll
                         for (int i = 1; i < N; ++i) {
-                            // (a pair outside `cur` reads some other word, or just past the plane: masked out below)
-                            const uint32_t word = lds_ld<uint32_t>(G::oW + (uint32_t)__popc(cur & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4);
-                            h |= word < thr[i] ? (1u << i) : 0u;
+                            // (a pair outside `cur` reads some other words, or just past the plane: masked out below)
+                            const uint32_t r = (uint32_t)__popc(cur & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4;
+                            const uint64_t u = uniform53(lds_ld<uint32_t>(G::oW + r), lds_ld<uint32_t>(G::oW + (uint32_t)(4 * B * 4) + r));
+                            h |= u < thr64[i] ? (1u << i) : 0u;
                         }
-                        hits |= h & cur;
+                        hits53 |= h & cur;
                         rest = m;
                     }
+                    n_attempts = (uint32_t)__popc(cand);
+                } else {
+                    // ---- overtakes: draw words ----
+                    // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4.  The first eight -- all that
+                    // all but a few wave-passes in a thousand need -- are drawn FIRST, into the eight rows of the W plane: the
+                    // stage below then fetches a pair's word the moment its row is known, and no array of addresses or of
+                    // candidate bits has to live across the Philox blocks (which cost a dozen registers themselves).
+                    {
+                        uint32_t o0, o1, o2, o3;
+                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass), k0l, k1l, o0, o1, o2, o3);
+                        lds_st<uint32_t>(w_row(0), o0);
+                        lds_st<uint32_t>(w_row(1), o1);
+                        lds_st<uint32_t>(w_row(2), o2);
+                        lds_st<uint32_t>(w_row(3), o3);
+                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 1), k0l, k1l, o0, o1, o2, o3);
+                        lds_st<uint32_t>(w_row(4), o0);
+                        lds_st<uint32_t>(w_row(5), o1);
+                        lds_st<uint32_t>(w_row(6), o2);
+                        lds_st<uint32_t>(w_row(7), o3);
+                    }
+                    // W-plane address of the NEXT attempt's word: a running sum over the candidates so far (row k of the plane
+                    // holds the word of the lane's k-th attempt), advanced inside ovt_threshold by the compare that makes
+                    // the pair a candidate
+                    uint32_t row = tid4;
+                    {
+                        constexpr int H = MCGP_PACE_BATCH;
+                        const uint32_t row_stride = (uint32_t)(B * 4);
+                        double pace_prev = 0.0;
 #pragma unroll
-                    for (int i = 1; i < N; ++i) {
-                        thr[i] = (hits >> i) & 1u;
-                        ow[i] = 0u;
+                        for (int h = 0; h < N; h += H) {
+                            MCGP_SCHED_FENCE();
+                            double pb[H], pd[H], pa[H];
+#pragma unroll
+                            for (int j = 0; j < H; ++j) {
+                                if (h + j < N) {
+                                    const uint32_t id16 = (pk[h + j] >> 6) & 0x3F0u;      // 16 x (32 dnf + driver)
+                                    const f64x2 bd = lds_ld_f64x2(G::oDrvB + id16);
+                                    pb[j] = bd.x;
+                                    pd[j] = bd.y;
+                                    pa[j] = lds_ld<double>(G::oDrsB + (pk[h + j] & k3Drs));
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < H; ++j) {
+                                const int i = h + j;
+                                if (i < N) {
+                                    // a retired car's pace is NaN (table): its two pairs compare false below (:511)
+                                    const double pace = pb[j] + (double)(pk[i] & k3AgeMask) * pd[j];
+                                    if (i > 0) {
+                                        const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520 (x 2^31)
+                                        // candidate iff dl > overtake_delta (:522); threshold min(ceil(dl), 2^31) (:523-524)
+                                        uint32_t next;
+                                        ovt_threshold(dl, od31, row, row_stride, thr[i], next);
+                                        // (a pair that is no candidate fetches the word of the next attempt, or one just past
+                                        //  the plane: its threshold is 0)
+                                        ow[i] = lds_ld<uint32_t>(G::oW + row);
+                                        row = next;
+                                    }
+                                    pace_prev = pace;
+                                }
+                            }
+                        }
+                        thr[0] = 0u;
+                        ow[0] = 0u;
+                    }
+                    const uint32_t words_end = row - tid4;          // = attempts of this lane x the row stride
+                    MCGP_STAT(0 + pass, words_end != 0u);
+                    if (words_end == 0u) break;
+                    n_attempts = words_end / (uint32_t)(B * 4);
+                    // A wave with a lane that has more than eight attempts takes the general path, 8 attempts at a time, and
+                    // leaves its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
+                    if (__builtin_expect(MCGP_ANY(words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
+                        // the candidate mask: a candidate's threshold is at least 1 (dl > overtake_delta >= 0: reg_kernel_serves
+                        // sends a negative delta -- attempts at a pace DEFICIT -- to the generic kernel)
+                        uint32_t cand = 0u;
+#pragma unroll
+                        for (int i = 1; i < N; ++i) cand |= thr[i] != 0u ? (1u << i) : 0u;
+                        uint32_t hits = 0u, rest = cand;
+#pragma unroll 1
+                        for (int chunk = 0; rest != 0u; ++chunk) {
+                            uint32_t m = rest;                                  // `rest` without its 8 lowest set bits
+#pragma unroll 1
+                            for (int k = 0; k < kWordRows && m != 0u; ++k) m &= m - 1u;
+                            const uint32_t cur = rest & ~m;                     // attempts 8 chunk .. 8 chunk + 7
+#pragma unroll 1
+                            for (int b = 0; b < 2; ++b) {
+                                uint32_t o0, o1, o2, o3;
+                                philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + 2 * chunk + b), k0l,
+                                              k1l, o0, o1, o2, o3);
+                                lds_st<uint32_t>(w_row(4 * b + 0), o0);
+                                lds_st<uint32_t>(w_row(4 * b + 1), o1);
+                                lds_st<uint32_t>(w_row(4 * b + 2), o2);
+                                lds_st<uint32_t>(w_row(4 * b + 3), o3);
+                            }
+                            uint32_t h = 0u;
+#pragma unroll
+                            for (int i = 1; i < N; ++i) {
+                                // (a pair outside `cur` reads some other word, or just past the plane: masked out below)
+                                const uint32_t word = lds_ld<uint32_t>(G::oW + (uint32_t)__popc(cur & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4);
+                                h |= word < thr[i] ? (1u << i) : 0u;
+                            }
+                            hits |= h & cur;
+                            rest = m;
+                        }
+#pragma unroll
+                        for (int i = 1; i < N; ++i) {
+                            thr[i] = (hits >> i) & 1u;
+                            ow[i] = 0u;
+                        }
                     }
                 }
                 // ---- overtakes: success test and write-back chain ----
@@ -1301,7 +1456,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 bool any_succ = false;
 #pragma unroll
                 for (int i = 1; i < N; ++i) {
-                    const bool hit = ow[i] < thr[i];
+                    const bool hit = WIDE ? ((hits53 >> i) & 1u) != 0u : ow[i] < thr[i];
                     const double nb = cum[i - 1] - 0.1;                        // max(0.1, ahead - 0.1), :528: reg_time_floor()
                     const double na = nb + 0.3;                                // :530
                     cum[i] = hit ? nb : cum[i];
@@ -1309,8 +1464,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     any_succ |= hit;
                 }
                 MCGP_STAT(4 + pass, any_succ);
-                MCGP_STAT(8, words_end / (uint32_t)(B * 4));
-                MCGP_TRACE_PASS(local, lap, pass, (int)(words_end / (uint32_t)(B * 4)));
+                MCGP_STAT(8, n_attempts);
+                MCGP_TRACE_PASS(local, lap, pass, (int)n_attempts);
+                (void)n_attempts;
                 if (!any_succ) break;
                 // ---- overtakes: re-sort ----
                 resort_after_overtakes<N>(cum, pk);     // sorted again for the next pass / _update_positions
@@ -1383,6 +1539,25 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     // retirement lists: one column per lane of the launch, N + 1 rows (reg_retire_ws_bytes)
     reg_simulate<N>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
                     retire_ws, (uint32_t)(gridDim.x * RegGeo<N>::B), (uint32_t)(blockIdx.x * RegGeo<N>::B));
+    __syncthreads();
+    reg_flush_hist<N>(smem, threadIdx.x, hist);
+}
+
+// The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): same launch geometry, same phases.
+template <int N>
+__global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
+race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
+                     uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
+                     uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,
+                     uint32_t *__restrict__ ticket, uint32_t *__restrict__ retire_ws, const double *__restrict__ norm53)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) __builtin_trap();
+    reg_load_tables<N>(P, smem, threadIdx.x);
+    __syncthreads();
+    reg_simulate<N, true>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
+                          retire_ws, (uint32_t)(gridDim.x * RegGeo<N>::B), (uint32_t)(blockIdx.x * RegGeo<N>::B),
+                          kTicketChunks, norm53);
     __syncthreads();
     reg_flush_hist<N>(smem, threadIdx.x, hist);
 }

@@ -63,7 +63,7 @@ class _Problem:
     """run_monte_carlo's arguments resolved to the dense tables of include/mcgp.h."""
 
     def __init__(self, config: RaceConfig, drivers, base_pace, tire_deg, driver_variance,
-                 driver_dnf_rates, track_condition, set_pop):
+                 driver_dnf_rates, track_condition, set_pop, deviates=32):
         if track_condition not in N.TRACK_ID:
             raise ValueError(f"track_condition must be 'dry', 'damp' or 'wet', got {track_condition!r}")
         self.drivers = [str(d) for d in drivers]
@@ -86,6 +86,9 @@ class _Problem:
             c.comp_optimal_laps[i] = int(info.get('optimal_laps', 30))
         c.pop_soft_hard = N.COMPOUND_ID[set_pop['SOFT_HARD']]
         c.pop_medium_hard = N.COMPOUND_ID[set_pop['MEDIUM_HARD']]
+        if deviates not in (32, 53):
+            raise ValueError(f'deviates must be 32 or 53, got {deviates!r}')
+        c.deviates = 1 if deviates == 53 else 0
 
         driver_dnf_rates = driver_dnf_rates or {}
         team_rate = [config.dnf_rates.get(config.driver_teams.get(d, 'Unknown'), 0.002)   # :263,286
@@ -106,8 +109,13 @@ class _Problem:
 class RaceSimulator:
     """Drop-in for the reference's RaceSimulator (:55-560) with the race loop on the GPU."""
 
-    def __init__(self, config: RaceConfig, device=0, set_pop: dict | None = None):
-        """`device`: a HIP device index (default 0), a list of indices, or 'all' (every visible device).  With more
+    def __init__(self, config: RaceConfig, device=0, set_pop: dict | None = None, deviates: int = 32):
+        """`deviates`: 32 (default) -- uniforms w / 2^32 and normals from a binary32 cubic table, the fast path -- or 53:
+        the reference's width, 53-bit uniforms and binary64 normals (reference :137,194,302,330,524), every draw keeping
+        the 32-bit mode's word as its leading bits; a priced option (include/mcgp.h: mcgp_config.deviates), built for
+        fields of 10, 20 and 21 cars.
+
+        `device`: a HIP device index (default 0), a list of indices, or 'all' (every visible device).  With more
         than one device a run_monte_carlo call is split by simulation id into contiguous shards, one host thread per
         device over the same C entry point, and the integer histograms are added on the host -- the whole node from the
         plain single-process call the reference's caller makes (reference src/predictor.py:264,283-291), with results
@@ -115,6 +123,7 @@ class RaceSimulator:
         listed more than once (shards then queue on that device).  The torchrun + RCCL path (distributed.py) is
         separate and unchanged."""
         self.config = config
+        self.deviates = int(deviates)
         if isinstance(device, str):
             if device != 'all':
                 raise ValueError(f"device must be an index, a list of indices or 'all', got {device!r}")
@@ -159,7 +168,7 @@ class RaceSimulator:
         if n < 1 or n > N.MAX_CARS:
             raise ValueError(f'number of drivers must be in [1, {N.MAX_CARS}], got {n}')
         return _Problem(self.config, drivers, base_pace, tire_deg, driver_variance, driver_dnf_rates,
-                        track_condition, self.set_pop)
+                        track_condition, self.set_pop, self.deviates)
 
     # ------------------------------------------------------------------ reference surface
     def run_monte_carlo(

@@ -191,6 +191,12 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+static inline double bits_to_double(unsigned long long b)
+{
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
 static inline float bits_to_float(uint32_t b)
 {
     float f;
@@ -232,9 +238,10 @@ float orc_normal_from_u32(uint32_t w)
  *     uniform  u53 = (w 2^21 + e) / 2^53                  in [w / 2^32, (w + 1) / 2^32)
  *     normal   sign = w >> 31, m = w & 0x7fffffff, tail probability p = (m 2^21 + e + 0.5) / 2^53
  *              (the 32-bit draw's (m + 0.5) / 2^32 refined), z = -+ Phi^-1(p) in binary64
- *              (Halley steps on libm erfc from the table value, |err| ~ 1e-16)
- * so a race simulated with both back-ends differs only by the refinement itself.  Not matched by any GPU
- * code; used by tools/deviate_bias.py and tests/test_oracle_golden.py only. */
+ *              (normal53_tail below: the degree-7 table form the device computes, |err| <= 3e-15; the erfc iteration
+ *              that follows is kept as an independent check of that table)
+ * so a race simulated with both back-ends differs only by the refinement itself.  The library's `deviates = 53` mode
+ * (include/mcgp.h) computes exactly this back-end on the GPU. */
 static double phi_inverse_tail(uint64_t q53, float z_start)
 {
     /* p = (q53 + 0.5) / 2^53 in (0, 0.5): lower-tail probability; returns z = Phi^-1(p) < 0.
@@ -257,6 +264,33 @@ static double phi_inverse_tail(uint64_t q53, float z_start)
 }
 
 double orc_phi_inverse_tail(uint64_t q53, float z_start) { return phi_inverse_tail(q53, z_start); }
+
+/* The binary64 deviate of the reference-width back-end, in the form the DEVICE computes it (csrc/race_common.hip.h:
+ * normal53_tail): a piecewise polynomial of degree 7 on log-spaced cells of the 52-bit tail index q, explicit fma
+ * only -- the same bits on every machine (tools/gen_normal53_table.py; |err| <= 3e-15 against Phi^-1, checked against
+ * the erfc iteration above by tests/test_oracle_golden.py).  Returns z0 = Phi^-1((q + 0.5) / 2^53) < 0. */
+#include "normal53_table.h"
+static double normal53_tail(uint64_t q)
+{
+    uint32_t row;
+    double t;
+    if (q < 16u) {
+        row = (uint32_t)q;
+        t = 0.0;
+    } else {
+        const int hb = 63 - __builtin_clzll(q);
+        const int sh = hb - 4;
+        const uint32_t k = (uint32_t)(q >> sh) & 15u;
+        const uint64_t r = q & (((uint64_t)1 << sh) - 1u);
+        t = ((double)r + 0.5) * ldexp(1.0, -sh);               /* exact: r < 2^47, a power of two */
+        row = 16u + 16u * (uint32_t)sh + k;
+    }
+    const unsigned long long *c = &mcgp_normal53_table_bits[(size_t)MCGP_NORMAL53_COEFFS * row];
+    double z = bits_to_double(c[MCGP_NORMAL53_COEFFS - 1]);
+    for (int d = MCGP_NORMAL53_COEFFS - 2; d >= 0; d--) z = fma(z, t, bits_to_double(c[d]));
+    return z;
+}
+double orc_normal53_tail(uint64_t q) { return normal53_tail(q); }
 
 /* ------------------------------------------------------------------------- */
 /* Random source seen by the race logic.  The logic asks for draws in the      */
@@ -322,7 +356,7 @@ static double philox_normal(const rng_t *r, uint32_t lap, uint32_t purpose, uint
     if (r->mode != MCGP_ORACLE_RNG_PHILOX53) return (double)z32;
     const uint64_t q = ((uint64_t)(w & 0x7fffffffu) << 21) | philox_extra21(r, lap, purpose, index, word);
     /* tail probability (m + 0.5) / 2^32 of the 32-bit draw refined to (q + 0.5) / 2^53 */
-    const double z0 = phi_inverse_tail(q, (w >> 31) ? -z32 : z32);
+    const double z0 = normal53_tail(q);
     return (w >> 31) ? -z0 : z0;
 }
 

@@ -94,6 +94,8 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 float orc_normal_from_u32(uint32_t w);
 /* Phi^-1((q53 + 0.5) / 2^53) for q53 < 2^52 (lower tail), Newton from z_start; exposed for unit tests. */
 double orc_phi_inverse_tail(uint64_t q53, float z_start);
+/* the same value in the form the device computes it: degree-7 table, explicit fma (normal53_table.h) */
+double orc_normal53_tail(uint64_t q53);
 
 /* Run n_sims simulations.
  *   grid_probs  n x n row-major [driver][slot]

@@ -48,14 +48,14 @@ def lib(variant=None):
     return _libs[variant]
 
 
-def run(case, n_sims, seed, sim_offset=0, set_pop=None, fixed_grid=None, variant=None):
+def run(case, n_sims, seed, sim_offset=0, set_pop=None, fixed_grid=None, variant=None, deviates=32):
     """(hist, orders) of the kernel source executed on the host for a golden-case dict."""
     from monte_carlo_gp_amd import RaceConfig
     from monte_carlo_gp_amd.simulation import RaceSimulator, _Problem, _dptr
     import oracle_py as O
     drivers = list(case['grid_probs'])
     p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
-                 case['driver_dnf_rates'], case['track_condition'], set_pop or O.load_cases()['set_pop'])
+                 case['driver_dnf_rates'], case['track_condition'], set_pop or O.load_cases()['set_pop'], deviates)
     g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
     n = p.n
     hist = np.zeros((n, n), np.uint64)

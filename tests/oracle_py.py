@@ -49,7 +49,7 @@ class OrcTrace(C.Structure):
 
 def build(force=False):
     """Compile the oracle if the shared object is missing or stale."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ('mcgp_oracle.c', 'mcgp_oracle.h', 'normal_table.h', 'frontend_exp.h', 'elo_update.h', 'Makefile')]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ('mcgp_oracle.c', 'mcgp_oracle.h', 'normal_table.h', 'normal53_table.h', 'frontend_exp.h', 'elo_update.h', 'Makefile')]
     if (force or not os.path.exists(LIB_PATH)
             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.check_call(['make', '-C', ORACLE_DIR, '-s', '-B'], stdout=subprocess.DEVNULL,
@@ -80,6 +80,8 @@ def lib():
         L.orc_normal_from_u32.argtypes = [C.c_uint32]
         L.orc_phi_inverse_tail.restype = C.c_double
         L.orc_phi_inverse_tail.argtypes = [C.c_uint64, C.c_float]
+        L.orc_normal53_tail.restype = C.c_double
+        L.orc_normal53_tail.argtypes = [C.c_uint64]
         L.orc_run.restype = C.c_int
         L.orc_run.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcDrivers), C.POINTER(C.c_double), C.c_int32,
                               C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,

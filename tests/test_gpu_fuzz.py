@@ -25,8 +25,10 @@ def _check(cases, names, n_sims):
         k = N.lib().mcgp_last_kernel_name(0).decode()
         if not os.environ.get('MCGP_FORCE_GENERIC'):
             # every configuration, certain retirements (X_all_out_lap2: probability >= 1) included, runs on the register
-            # kernel: a retirement lap is drawn once per race, and p >= 1 is just a survival threshold of 0
-            assert k.startswith('mcgp::race_kernel_reg<'), (name, k)
+            # kernel -- a retirement lap is drawn once per race, p >= 1 is just a survival threshold of 0 -- except a
+            # NEGATIVE overtake_delta (X_all_attempt: attempts at a pace deficit), which reg_kernel_serves hands to the
+            # generic kernel
+            assert k.startswith('mcgp::race_kernel_reg<') != (c['config']['overtake_delta'] < 0), (name, k)
         kernels.add(k)
     return kernels
 

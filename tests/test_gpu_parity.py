@@ -408,3 +408,52 @@ def test_a_season_of_races_in_one_launch(require_gpu):
     # empty and degenerate batches
     assert run_monte_carlo_batch([], n_sims) == []
     assert run_monte_carlo_batch([problem('S60', 1, 0)], 0)[0][0] == {}
+
+
+def test_more_than_eight_attempts_in_a_pass(require_gpu):
+    """overtake_delta = 0: every pair with a pace advantage attempts, so most passes have a lane with more than the
+    eight attempts the W plane holds and the wave takes the general path, eight at a time (reference :516-524)."""
+    import copy
+    from monte_carlo_gp_amd import _native as N
+    case = copy.deepcopy(O.load_case('S60'))
+    case['config']['overtake_delta'] = 0.0
+    ref = O.Problem(case).run(3000, rng=O.RNG_PHILOX, seed=5, want_orders=True)
+    hist, _, orders = product_run(case, 3000, 5, orders=True)
+    assert N.lib().mcgp_last_kernel_name(0).decode() == 'mcgp::race_kernel_reg<20>'
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+
+
+@pytest.mark.parametrize('name', ['S60', 'S78', 'S50', 'EVT', 'HET', 'DMP', 'WET', 'N10'])
+def test_reference_width_deviates_match_the_oracle(require_gpu, name):
+    """deviates = 53 on the device -- 53-bit uniforms and binary64 normals, the reference's width
+    (reference src/simulation.py:137,194,302,330,524) -- is bit-identical to the oracle's PHILOX53 back-end on the 8
+    golden cases, finishing orders and histograms, ragged offsets included; and it is a different kernel from the
+    default one."""
+    from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N
+    case = O.load_case(name)
+    n_sims, seed, off = 3000, 42, 123_456_789_012
+    ref = O.Problem(case).run(n_sims, rng=O.RNG_PHILOX53, seed=seed, sim_offset=off, want_orders=True)
+    sim = RaceSimulator(RaceConfig(**case['config']), set_pop=O.load_cases()['set_pop'], deviates=53)
+    probs, orders = sim.run_monte_carlo(n_sims, case['grid_probs'], case['base_pace'], case['tire_deg'],
+                                        case['driver_variance'], case['driver_dnf_rates'], seed=seed,
+                                        track_condition=case['track_condition'], sim_offset=off, return_orders=True)
+    assert N.lib().mcgp_last_kernel_name(0).decode().startswith('mcgp::race_kernel_reg_wide<')
+    bad = np.nonzero((orders != ref['orders']).any(axis=1))[0]
+    assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
+    assert np.array_equal(sim.last_histogram, ref['hist'])
+
+
+def test_reference_width_deviates_are_built_for_three_field_sizes(require_gpu):
+    from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N
+    case = O.load_case('S60')
+    keep = list(case['grid_probs'])[:7]
+    sub = {k: {d: (v[:7] if k == 'grid_probs' else v) for d, v in case[k].items() if d in keep}
+           for k in ('grid_probs', 'base_pace', 'tire_deg', 'driver_variance', 'driver_dnf_rates')}
+    sim = RaceSimulator(RaceConfig(**case['config']), deviates=53)
+    with pytest.raises(N.McgpError) as e:
+        sim.run_monte_carlo(100, sub['grid_probs'], sub['base_pace'], sub['tire_deg'], sub['driver_variance'],
+                            sub['driver_dnf_rates'], seed=1)
+    assert e.value.code == -1 and '10, 20 and 21' in str(e.value)
+    with pytest.raises(ValueError):
+        RaceSimulator(RaceConfig(**case['config']), deviates=64).run_monte_carlo(
+            10, case['grid_probs'], case['base_pace'], case['tire_deg'], case['driver_variance'])

@@ -120,3 +120,27 @@ def test_sample_grid_exact_path_equals_the_fast_path(name):
     _, fast = K.run(case, 400, 7)
     _, exact = K.run(case, 400, 7, variant='grid_exact')
     assert np.array_equal(fast, exact) and np.array_equal(exact, ref['orders'])
+
+
+def test_more_than_eight_attempts_in_a_pass():
+    """overtake_delta = 0: every pair with a pace advantage attempts, so most passes have a lane with more than the
+    eight attempts the W plane holds and take the general path, eight at a time (reference :516-524)."""
+    import copy
+    case = copy.deepcopy(O.load_case('S60'))
+    case['config']['overtake_delta'] = 0.0
+    ref = O.Problem(case).run(300, rng=O.RNG_PHILOX, seed=5, want_orders=True)
+    hist, orders = K.run(case, 300, 5)
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+
+
+@pytest.mark.parametrize('name', ['S60', 'S78', 'S50', 'EVT', 'HET', 'DMP', 'WET', 'N10'])
+def test_reference_width_deviates_match_the_oracle(name):
+    """deviates = 53 (reg_simulate<N, true>): 53-bit uniforms and binary64 normals, the reference's width (reference
+    :137,194,302,330,524), against the oracle's PHILOX53 back-end -- same words, same companion blocks, same table."""
+    case = O.load_case(name)
+    n_sims = 400
+    ref = O.Problem(case).run(n_sims, rng=O.RNG_PHILOX53, seed=42, want_orders=True)
+    hist, orders = K.run(case, n_sims, 42, deviates=53)
+    bad = np.nonzero((orders != ref['orders']).any(axis=1))[0]
+    assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
+    assert np.array_equal(hist, ref['hist'])

@@ -28,6 +28,7 @@ unsigned long long emu_trace_sims = 0, emu_trace_laps = 0;
 
 #include "../../monte_carlo_gp_amd/csrc/params_build.h"
 #include "../../monte_carlo_gp_amd/csrc/race_kernel_reg.hip.h"
+#include "../../monte_carlo_gp_amd/csrc/normal53_table.h"
 
 #include <vector>
 
@@ -63,6 +64,23 @@ static int run_size(const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offse
                     uint8_t *orders, const uint8_t *fixed_grid)
 {
     if constexpr (N % EMU_PARTS == EMU_PART) {
+        // the reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53) exists for the sizes the library builds it for
+        if (kp.wide) {
+            if constexpr (N == 10 || N == 20 || N == 21) {
+                constexpr uint32_t B = mcgp::RegGeo<N>::B;
+                const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
+                for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N>(&kp, mcgp::smem, t);
+                std::vector<uint32_t> retire_ws((size_t)(N + 1) * B);
+                for (uint32_t t = 0; t < B; ++t)
+                    mcgp::reg_simulate<N, true>(&kp, mcgp::smem, t, nullptr, n_sims, sim_offset, (uint32_t)seed,
+                                                (uint32_t)(seed >> 32), orders, fixed_grid, n_chunks, retire_ws.data(), B, 0u,
+                                                mcgp::kTicketChunks, reinterpret_cast<const double *>(mcgp_normal53_table_bits));
+                for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N>(mcgp::smem, t, hist);
+                return 0;
+            } else {
+                return -3;
+            }
+        }
         // one block at a time; inside a block the three phases of the kernel run for every "thread" in turn
         constexpr uint32_t B = mcgp::RegGeo<N>::B;
         const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);

@@ -32,6 +32,18 @@ inline void __syncthreads() {}
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+inline int __clzll(long long v) { return v == 0 ? 64 : __builtin_clzll((unsigned long long)v); }
+inline double __hiloint2double(int hi, int lo)
+{
+    const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+    double d;
+    std::memcpy(&d, &u, 8);
+    return d;
+}
+inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b)
+{
+    return (unsigned long long)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
+}
 inline int __double2hiint(double x)
 {
     uint64_t u;
