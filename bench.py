@@ -240,14 +240,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run_workload(name, steps, warmup, with_orders=False):
+    def run_workload(name, steps, warmup, with_orders=False, deviates=32):
         """`warmup` untimed steps, then exactly `steps` timed steps between barrier + synchronize pairs."""
         case, set_pop = load_workload(name)
         cfg = RaceConfig(**case['config'])
         drivers = list(case['grid_probs'].keys())
         n, L = len(drivers), cfg.total_laps
         prob = _Problem(cfg, drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
-                        case['driver_dnf_rates'], case['track_condition'], set_pop)
+                        case['driver_dnf_rates'], case['track_condition'], set_pop, deviates)
         grid = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
         seed = case['seed']
         d_hist = torch.zeros(n * n, dtype=torch.int64, device=dev)       # running total (all ranks, all steps)
@@ -382,7 +382,10 @@ def main():
             'dtype': 'f64',
             'dtype_note': 'race state and every comparison in IEEE binary64 (as the reference); random deviates carry '
                           '32 bits: uniforms w/2^32, normals from a binary32 piecewise-cubic inverse CDF (|err| <= 4.8e-7); '
-                          'measured effect of that substitution on results: profiles/r3_deviate_bias.txt',
+                          'measured effect of that substitution on results: profiles/r4_deviate_bias.txt (GPU, 10^9 simulations '
+                          'against the library\'s own 53-bit mode, which bench.py prices as `deviates53`); stated tolerance of a '
+                          'win probability against the reference: 4 SE of a 2x10^7 / 10^8-simulation pair = 0.05 pp at p = 0.5 '
+                          '(tests/test_gpu_scale.py)',
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {n} drivers, {L} laps, {per_gpu} simulations per GPU per step, '
                                    f'fixed Elo grid, seed {r["seed"]}',
@@ -400,6 +403,15 @@ def main():
             'metric': f"race-simulations/sec ({w78['n']} drivers, {w78['L']} laps; Monaco parameters, BASELINE configs[2])",
             'value': w78['total'] / w78['elapsed'], 'steps': 3, 'kernel_ms_avg': w78['kernel_ms'],
             'car_laps_per_s': per_gpu * w78['n'] * w78['L'] / (w78['kernel_ms'] * 1e-3)}}
+        # what the reference's deviate width costs on this device: the same workload with 53-bit uniforms
+        # and binary64 normals (mcgp_config.deviates = MCGP_DEVIATES_53; bit-identical to the oracle's PHILOX53 back-end)
+        w53 = run_workload(args.workload, 3, 1, deviates=53)
+        out['deviates53'] = {'value': w53['total'] / w53['elapsed'], 'unit': 'race-simulations/s', 'steps': 3,
+                             'kernel_ms_avg': w53['kernel_ms'], 'kernel': w53['kernel'],
+                             'slowdown_vs_32bit_deviates': w53['kernel_ms'] / kavg_ms,
+                             'note': 'every draw keeps the 32-bit word as its leading bits and takes 21 more from a companion '
+                                     'Philox block; normals from a degree-7 binary64 table in device memory; effect on '
+                                     'results: profiles/r4_deviate_bias.txt (GPU, 10^9 simulations)'}
         bytes_written = per_gpu * wo['n']
         out['orders_mode'] = {'value': wo['total'] / wo['elapsed'], 'unit': 'race-simulations/s', 'steps': 3,
                               'kernel_ms_avg': wo['kernel_ms'], 'bytes_per_launch': bytes_written,

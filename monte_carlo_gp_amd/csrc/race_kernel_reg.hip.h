@@ -55,6 +55,9 @@
 #ifndef MCGP_GRID_EXACT
 #define MCGP_GRID_EXACT 0
 #endif
+#ifndef MCGP_RESORT_ROUNDS
+#define MCGP_RESORT_ROUNDS 0
+#endif
 #ifndef MCGP_COOPERATIVE_EVENTS
 #define MCGP_COOPERATIVE_EVENTS 1
 #endif
@@ -365,8 +368,20 @@ __device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N]
 template <int N>
 __device__ __forceinline__ void resort_after_overtakes(double (&cum)[N], uint32_t (&pk)[N])
 {
+#if MCGP_RESORT_ROUNDS
+    // experiment: odd-even transposition rounds (independent comparators within a round) instead of the two bubble passes
+#pragma unroll
+    for (int r = 0; r < MCGP_RESORT_ROUNDS; ++r) {
+#pragma unroll
+        for (int i = (r & 1); i + 1 < N; i += 4) {
+            if (i + 3 < N) cmpx_time2(cum[i], pk[i], cum[i + 1], pk[i + 1], cum[i + 2], pk[i + 2], cum[i + 3], pk[i + 3]);
+            else cmpx_time(cum[i], pk[i], cum[i + 1], pk[i + 1]);
+        }
+    }
+#else
     bubble_forward<N, 0>(cum, pk);                 // (0,1), (1,2), .. (N-2,N-1)
     bubble_backward<N, N - 2>(cum, pk);            // (N-3,N-2), .. (0,1): the last slot already holds the maximum
+#endif
     const bool strict = strictly_increasing<N>(cum);
     MCGP_STAT(14, !strict);
     if (__builtin_expect(!strict, 0)) {

@@ -17,7 +17,8 @@ _libs = {}
 # named diagnostic variants of the host build: extra -D flags of csrc/race_kernel_reg.hip.h
 VARIANTS = {
     None: [],
-    'grid_exact': ['-DMCGP_GRID_EXACT=1'],      # _sample_grid takes the exact (dividing) path for every draw
+    'grid_exact': ['-DMCGP_GRID_EXACT=1'],
+    'rr4': ['-DMCGP_RESORT_ROUNDS=4'], 'rr6': ['-DMCGP_RESORT_ROUNDS=6'], 'rr3': ['-DMCGP_RESORT_ROUNDS=3'],      # _sample_grid takes the exact (dividing) path for every draw
 }
 
 

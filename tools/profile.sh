@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes for one workload of bench.py on the GPU box (run through gpurun); raw output goes to
-# gpurun_out/<tag>_<workload>_<pass>/, tools/summarize_r2.py turns it into the tracked files under profiles/.
-#   tools/profile_r3.sh r2 S60 [extra bench.py flags, e.g. --orders]
+# gpurun_out/<tag>_<workload>_<pass>/, tools/summarize_profiles.py turns it into the tracked files under profiles/.
+#   tools/profile.sh r4 S60 [extra bench.py flags, e.g. --orders]
 # Passes (counters never share a run with tracing; FETCH_SIZE / WRITE_SIZE / SQ sets in separate runs as
 # MI355X_MICROARCH.md prescribes; the profiled program is python3 itself, directly after `--`):
 #   stats  --kernel-trace --stats                    kernel durations
@@ -28,7 +28,7 @@ run() {   # name, rocprofv3 options...
 # python starts, and a GPU-initialised process must not fork + exec make
 python3 -c "import sys; sys.path.insert(0, 'tests')
 from monte_carlo_gp_amd import _native as N; import oracle_py as O
-N.build(); O.build(); print(N.source_hash())" > gpurun_out/${tag}_${wl}${sfx}_hash.txt
+N.build(); O.build(); print(N.build_hash())" > gpurun_out/${tag}_${wl}${sfx}_hash.txt
 run stats --kernel-trace --stats
 run sq1 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
 run sq2 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU
