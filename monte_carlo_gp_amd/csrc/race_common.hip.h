@@ -112,22 +112,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 template <typename RowFn>
 __device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
 {
-    const uint32_t m = w & 0x7fffffffu;
-    const bool small = m < 16u;
-    const uint32_t mm = small ? 16u : m;
-    const int sh = 27 - __clz((int)mm);                 // floor(log2 mm) - 4
-    const uint32_t k = (mm >> sh) & 15u;
-    const uint32_t r = mm & ((1u << sh) - 1u);
-    // (for m < 16 this t is 0.5 where the oracle uses 0: the 16 tail rows hold a constant, c1 = c2 = c3 = +0.0, and
-    //  fma(0, t, c) = c exactly, so no select -- which hipcc turns into a branch that cuts the caller's code into
-    //  basic blocks -- is needed)
-    const float t = ((float)r + 0.5f) * __uint_as_float((uint32_t)(127 - sh) << 23);
-    const uint32_t row = small ? m : 16u + 16u * (uint32_t)sh + k;
-    const float4 c = row_of(row);
-    float z = __builtin_fmaf(c.w, t, c.z);
-    z = __builtin_fmaf(z, t, c.y);
-    z = __builtin_fmaf(z, t, c.x);
-    return (w >> 31) ? -z : z;
+    // m + 16 has its leading one in bit 4 .. 31: c = clz picks the octave, the next four bits the cell, the rest is the
+    // offset inside the cell -- no special case for the smallest m, no select (tools/gen_normal_table.py)
+    const uint32_t mm = (w & 0x7fffffffu) + 16u;
+    const uint32_t c = (uint32_t)__clz((int)mm);
+    const uint32_t x = mm << c;
+    const uint32_t row = 16u * c + ((x >> 27) & 15u);
+    const float t = (float)(((x & 0x07ffffffu) << 1) | (1u << c));          // cell coordinate x 2^28
+    const float4 cf = row_of(row);
+    float z = __builtin_fmaf(cf.w, t, cf.z);
+    z = __builtin_fmaf(z, t, cf.y);
+    z = __builtin_fmaf(z, t, cf.x);
+    // z0 = Phi^-1(tail probability) is negative (or -0): the sign bit of w flips it
+    return __uint_as_float(__float_as_uint(z) ^ (w & 0x80000000u));
 }
 
 // Reference-width normal: z0 = Phi^-1((q + 0.5) / 2^53) < 0 for the 52-bit tail index q, degree-7 polynomial on

@@ -209,24 +209,17 @@ static inline float bits_to_float(uint32_t b)
  * kernel evaluates the same expression and gets the same bits. */
 float orc_normal_from_u32(uint32_t w)
 {
-    const uint32_t m = w & 0x7fffffffu;
-    uint32_t row;
-    float t;
-    if (m < 16u) {
-        row = m;
-        t = 0.0f;
-    } else {
-        const int hb = 31 - __builtin_clz(m);
-        const int sh = hb - 4;
-        const uint32_t k = (m >> sh) & 15u;
-        const uint32_t r = m & ((1u << sh) - 1u);
-        t = ((float)r + 0.5f) * bits_to_float((uint32_t)(127 - sh) << 23);
-        row = 16u + 16u * (uint32_t)sh + k;
-    }
-    const unsigned int *c = &mcgp_normal_table_bits[4 * row];
-    float z = __builtin_fmaf(bits_to_float(c[3]), t, bits_to_float(c[2]));
-    z = __builtin_fmaf(z, t, bits_to_float(c[1]));
-    z = __builtin_fmaf(z, t, bits_to_float(c[0]));
+    /* m + 16 has its leading one in bit 4 .. 31: c = clz picks the octave, the next four bits the cell, the rest is
+     * the offset inside the cell (tools/gen_normal_table.py: no special case for the smallest m) */
+    const uint32_t mm = (w & 0x7fffffffu) + 16u;
+    const int c = __builtin_clz(mm);
+    const uint32_t x = mm << c;
+    const uint32_t row = 16u * (uint32_t)c + ((x >> 27) & 15u);
+    const float t = (float)(((x & 0x07ffffffu) << 1) | (1u << c));          /* cell coordinate x 2^28 */
+    const unsigned int *cf = &mcgp_normal_table_bits[4 * row];
+    float z = __builtin_fmaf(bits_to_float(cf[3]), t, bits_to_float(cf[2]));
+    z = __builtin_fmaf(z, t, bits_to_float(cf[1]));
+    z = __builtin_fmaf(z, t, bits_to_float(cf[0]));
     return (w >> 31) ? -z : z;
 }
 

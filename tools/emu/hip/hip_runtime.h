@@ -50,6 +50,12 @@ inline int __double2hiint(double x)
     std::memcpy(&u, &x, 8);
     return (int)(uint32_t)(u >> 32);
 }
+inline uint32_t __float_as_uint(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
 inline float __uint_as_float(uint32_t u)
 {
     float f;
