@@ -6,10 +6,11 @@
 #   DUP=k   run section k twice (idempotent, results unchanged): its cost shows as a time difference
 #           (1 sorting network after the lap step, 4 _update_positions, 8 re-sort after an overtake pass, 16 event Philox block)
 #   SKIP=k  leave section k out (results wrong): timing only
-#           (1 overtake passes, 2 event handling, 4 grid sampling, 8 laps 2..L, 16 sorting network, 32 _update_positions, 64 lap step)
+#           (1 overtake passes, 2 event handling, 4 grid sampling, 8 laps 2..L, 16 sorting network, 32 _update_positions, 64 lap step,
+#            256 the retirement pre-draw -- nobody retires after lap 1 --, 512 the per-lap retirement handler -- likewise)
 set -e
 cd "$(dirname "$0")/.."
-VARIANTS=${VARIANTS:-"DUP=0 DUP=1 DUP=4 DUP=8 DUP=16 SKIP=1 SKIP=2 SKIP=4 SKIP=8 SKIP=16 SKIP=32 SKIP=64"}
+VARIANTS=${VARIANTS:-"DUP=0 DUP=1 DUP=4 DUP=8 DUP=16 SKIP=1 SKIP=2 SKIP=4 SKIP=8 SKIP=16 SKIP=32 SKIP=64 SKIP=256 SKIP=512"}
 case "$1" in
 build)
   mkdir -p abl

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction-class mix of the register kernel's lap loop (N = 20) and the VALU issue ceiling it implies.
 
-    python tools/valu_mix.py [listing.s]      (default: compiles reg_inst.hip with -gline-tables-only)   -> profiles/r3_valu_mix.json
+    python tools/valu_mix.py [listing.s]      (default: compiles reg_inst.hip with -gline-tables-only)   -> profiles/r4_valu_mix.json
 
 Classes and their cost come from tools/valu_peak.hip (profiles/r3_valu_peak.json, wall-clock measurements; the 4-waves-per-SIMD column is used: 2, 4 and 8 agree within 3 %): binary64 operations and every VOP3-encoded (`_e64`, three-operand or SGPR-mask) or 64-bit integer
 instruction occupy a SIMD for ~4.15 cycles per wave64 instruction; VOP1 / VOP2 32-bit instructions (`_e32`) for ~2.2.
@@ -26,38 +26,36 @@ def main():
                                '-o', path, os.path.join(ROOT, 'monte_carlo_gp_amd', 'csrc', 'reg_inst.hip')],
                               stderr=subprocess.DEVNULL)
     src = open(SRC).read().split('\n')
-    lo = next(i for i, l in enumerate(src, 1) if 'for (int lap = 2;' in l)
-    hi = next(i for i, l in enumerate(src, 1) if '// ================= classification' in l)
-    # rarely executed general paths inside the loop, by source text
-    cold = [i for i, l in enumerate(src, 1) if 'transposition_sort<N>(cum, pk)' in l or 'MCGP_ANY(n_cand > kWordRows)' in l]
-    cold_ranges = []
-    for i in cold:
-        if 'MCGP_ANY' in src[i - 1]:
-            j = next(k for k in range(i, hi) if src[k - 1].startswith('                } else {'))
-            cold_ranges.append((i, j))
+    find = lambda text: next(i for i, l in enumerate(src, 1) if text in l)
+    lo, hi = find('for (int lap = 2;'), find('// ================= classification')
+    # rarely executed general path inside the loop (a lane with more than eight attempts in a pass), by source text
+    g0 = find('// A wave with a lane that has more than eight attempts')
+    g1 = next(i for i in range(g0, hi) if src[i - 1].startswith('                // ---- overtakes: success test'))
     # ... and by function: the exact tie-aware sort and its order tests (the fallback of both sorts)
-    cold_fn = []
+    cold_fn = set()
     for i, l in enumerate(src, 1):
-        if re.search(r'void transposition_sort\(|bool in_order\(|bool even_pairs_in_order\(|bool ties_in_order\(', l):
+        if re.search(r'void transposition_sort\(|bool in_order\(|bool even_pairs_in_order\(|bool ties_in_order\(|^__device__ __forceinline__ bool cmpx\(', l):
             j = next(k for k in range(i, len(src)) if src[k - 1] == '}')
-            cold_fn.append((i, j))
-    in_cold = lambda n: any(a <= n <= b for a, b in cold_ranges)
-    in_cold_fn = lambda n: any(a <= n <= b for a, b in cold_fn)
-    cur, classes, ops = None, collections.Counter(), collections.Counter()
-    for line in open(path):
+            cold_fn.update(range(i, j + 1))
+    # the listing holds three kernels (default, reference-width, batch): the default one only
+    text = open(path).read()
+    funcs = re.split(r'\n(?=_ZN4mcgp\w+:)', text)
+    body = next(f for f in funcs if f.startswith('_ZN4mcgp15race_kernel_regILi20'))
+    cur, cold, classes, ops = None, False, collections.Counter(), collections.Counter()
+    for line in body.split('\n'):
         s = line.strip()
         m = re.match(r'\.loc\s+(\d+)\s+(\d+)', s)
         if m:
-            chain = re.findall(r'race_kernel_reg\.hip\.h:(\d+):', s)
-            cur = int(chain[-2]) if len(chain) >= 2 else int(m.group(2))
-            inner = int(m.group(2))
+            chain = [int(x) for x in re.findall(r'race_kernel_reg\.hip\.h:(\d+):', s)]
+            cur = chain[-2] if len(chain) >= 2 else int(m.group(2))
+            cold = any(x in cold_fn for x in chain)
             continue
         m = re.match(r'(v_\w+)', s)
-        if not m or cur is None or not (lo <= cur <= hi) or in_cold(cur) or in_cold_fn(inner):
+        if not m or cur is None or not (lo <= cur < hi) or cold or g0 <= cur < g1:
             continue
         op = m.group(1)
-        four = ('f64' in op or op.endswith('_e64') or 'u64' in op or 'b64' in op or 'i64' in op or
-                re.match(r'v_(bfe|lshl_add|lshl_or|and_or|or3|xor3|add3|mad_|bfi|alignbit|perm|med3|min3|max3|cndmask_b32_e64|readlane|writelane|mbcnt)', op) is not None
+        four = (('f64' in op or op.endswith('_e64') or 'u64' in op or 'b64' in op or 'i64' in op or
+                 re.match(r'v_(bfe|lshl_add|lshl_or|and_or|or3|xor3|add3|mad_|bfi|alignbit|perm|med3|min3|max3|cndmask_b32_e64|readlane|writelane|mbcnt)', op) is not None)
                 and not op.endswith('_e32'))
         classes['4-cycle class' if four else '2-cycle class'] += 1
         ops[op] += 1
@@ -75,7 +73,7 @@ def main():
     from monte_carlo_gp_amd import _native as N
     out['source_hash'] = N.source_hash()
     out['costs_from'] = 'profiles/r3_valu_peak.json (tools/valu_peak.hip), 4 waves per SIMD'
-    with open(os.path.join(ROOT, 'profiles', 'r3_valu_mix.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'profiles', 'r4_valu_mix.json'), 'w') as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Every workload of bench.py on one box (kernel ms from the library's hipEvents):  tools/workloads.sh > profiles/r3_workloads.jsonl
+# Every workload of bench.py on one box (kernel ms from the library's hipEvents):  tools/workloads.sh > profiles/r4_workloads.jsonl
 cd "$(dirname "$0")/.."
 for wl in ${WORKLOADS:-S60 S78 S50 EVT HET DMP WET N10 N22 N25}; do
   python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
