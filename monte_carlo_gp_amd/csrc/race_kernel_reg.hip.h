@@ -957,7 +957,13 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     const uint32_t out_lap = 2u + survived[j];
                     if (out_lap <= (uint32_t)L && !(MCGP_SKIP & 256)) {
                         const uint32_t key = (out_lap << 5) | (uint32_t)d;
-                        retire_ws[(size_t)n_out * ws_stride] = key;
+                        // the list in device memory is only ever read by a lane with MORE than two retirements: the
+                        // first two are written when a third turns up (about one race in thirteen), not before
+                        if (n_out == 2u) {
+                            retire_ws[0] = k1;
+                            retire_ws[(size_t)ws_stride] = k2;
+                        }
+                        if (n_out >= 2u) retire_ws[(size_t)n_out * ws_stride] = key;
                         ++n_out;
                         const uint32_t hi = key > k1 ? key : k1;
                         k1 = key < k1 ? key : k1;
@@ -965,7 +971,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     }
                 }
             }
-            retire_ws[(size_t)N * ws_stride] = n_out;
+            if (n_out > 2u) retire_ws[(size_t)N * ws_stride] = n_out;
             next_out = k1 | (k2 << 16) | (n_out > 2u ? 0x80000000u : 0u);
         }
 
