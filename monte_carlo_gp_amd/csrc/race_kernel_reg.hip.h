@@ -447,7 +447,7 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #define MCGP_STEP_BATCH 4          // slots whose LDS gathers (and Philox blocks) are in flight together in the lap step
 #endif
 #ifndef MCGP_PACE_BATCH
-#define MCGP_PACE_BATCH 10         // slots whose pace gathers are in flight together in an overtake pass
+#define MCGP_PACE_BATCH 5          // slots whose pace gathers are in flight together in an overtake pass (10: same speed, 52 B of spills against 20)
 #endif
 
 // A lower bound of every lap time of the problem, lap 1 included (reference :317-332, :301-306), from the inputs alone:
@@ -984,7 +984,12 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             // invariant part of every Philox block of the loop body (round 1 depends on the id and the block's
             // constant address only) out of the lap loop -- a dozen blocks x 3 registers held across the whole race.
             // Within the lap the shared part is still computed once.
-            uint32_t c0l = c0, c1l = c1;
+            // (re-derived from the wave's chunk number -- scalar -- and the lane number rather than copied from c0 / c1:
+            //  the simulation id then needs no register of its own across the lap loop)
+            uint32_t lane_l = tid;
+            pin(lane_l);
+            const uint64_t sim_l = sim_offset + ((uint64_t)chunk * 64ull + (uint64_t)(lane_l & 63u));
+            uint32_t c0l = (uint32_t)sim_l, c1l = (uint32_t)(sim_l >> 32);
             pin(c0l);
             pin(c1l);
             // Likewise the key: its ten round keys (seed + r x constant, twenty SGPRs) are worked out per lap from an opaque
@@ -1386,8 +1391,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     uint32_t row = tid4;
                     {
                         constexpr int H = MCGP_PACE_BATCH;
-                        const uint32_t row_stride = (uint32_t)(B * 4);
-                        double pace_prev = 0.0;
+                            double pace_prev = 0.0;
 #pragma unroll
                         for (int h = 0; h < N; h += H) {
                             MCGP_SCHED_FENCE();
@@ -1412,7 +1416,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                         const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520 (x 2^31)
                                         // candidate iff dl > overtake_delta (:522); threshold min(ceil(dl), 2^31) (:523-524)
                                         uint32_t next;
-                                        ovt_threshold(dl, od31, row, row_stride, thr[i], next);
+                                        ovt_threshold<(uint32_t)(B * 4)>(dl, od31, row, thr[i], next);
                                         // (a pair that is no candidate fetches the word of the next attempt, or one just past
                                         //  the plane: its threshold is 0)
                                         ow[i] = lds_ld<uint32_t>(G::oW + row);

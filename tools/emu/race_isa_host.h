@@ -95,8 +95,10 @@ inline uint32_t next_ticket(uint32_t *, uint32_t tid, uint32_t turn, int waves) 
 inline void sched_fence() {}
 inline double ceil_f64(double x) { return std::ceil(x); }
 inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-inline void ovt_threshold(double dl, double od, uint32_t row, uint32_t stride, uint32_t &thr, uint32_t &next)
+template <uint32_t STRIDE>
+inline void ovt_threshold(double dl, double od, uint32_t row, uint32_t &thr, uint32_t &next)
 {
+    const uint32_t stride = STRIDE;
     const bool c = dl > od;
     thr = c ? min_u32(cvt_u32_f64_sat(std::ceil(dl)), 0x80000000u) : 0u;
     next = row + (c ? stride : 0u);
