@@ -369,7 +369,7 @@ KernelFn select_kernel(const mcgp::KParams &kp, bool *is_reg)
 // block size and LDS footprint are compile-time functions of the field size (RegGeo<N>, shared with the
 // kernel); the number of blocks per CU follows from LDS and the kernel's register allocation.
 void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kernel, uint64_t n_sims, uint32_t *grid,
-                     uint32_t *block, uint32_t *lds)
+                     uint32_t *block, uint32_t *lds, int reg_waves = 0 /* 0: the register kernel's default block shape */)
 {
     // waves per CU the kernel's register allocation admits: 4 SIMDs x floor(512 / VGPRs, granule 8), at most 8 each
     int reg_cap = 8;
@@ -386,7 +386,7 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kerne
     int waves = 1, blocks_per_cu = 1;
     size_t bytes = 0;
     if (is_reg) {
-        waves = mcgp::reg_block_waves((int)n);
+        waves = reg_waves ? reg_waves : mcgp::reg_block_waves((int)n);
         bytes = mcgp::shared_lds_bytes_reg((int)n) + (size_t)waves * 64 * mcgp::per_thread_lds_bytes_reg((int)n);
     } else {
         const size_t per_wave = 64 * mcgp::per_thread_lds_bytes((int)n);
@@ -530,7 +530,8 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     uint32_t grid = 0, block = 0, lds = 0;
     for (uint64_t done = 0; done < n_sims; done += cap) {
         const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
-        launch_geometry(c, (uint32_t)kp.n, is_reg, wide ? reinterpret_cast<KernelFn>(wide) : kernel, m, &grid, &block, &lds);
+        launch_geometry(c, (uint32_t)kp.n, is_reg, wide ? reinterpret_cast<KernelFn>(wide) : kernel, m, &grid, &block, &lds,
+                        wide ? mcgp::kWideBlockWaves : 0);
         // units of work: the register kernel's waves claim chunks of 64 simulations from the stream's counter, a block
         // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
         const uint64_t unit = is_reg ? 64u : block;

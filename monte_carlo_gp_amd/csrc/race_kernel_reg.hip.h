@@ -138,9 +138,12 @@ __host__ __device__ constexpr int reg_block_waves(int n)
 // device memory the kernel wants for the lanes' retirement lists: (n + 1) words per lane of the launch
 __host__ __device__ constexpr size_t reg_retire_ws_bytes(int n, size_t lanes) { return (size_t)(n + 1) * lanes * 4; }
 
-template <int N>
+// (WAVES: the default is the block shape measured best for the field size; the reference-width build runs at 2 waves per
+//  SIMD -- 256 registers instead of 168, which its 64-bit thresholds and binary64 deviates want -- in blocks of 8 waves)
+constexpr int kWideBlockWaves = 8;
+template <int N, int WAVES = reg_block_waves(N)>
 struct RegGeo {
-    static constexpr int kWaves = reg_block_waves(N);
+    static constexpr int kWaves = WAVES;
     static constexpr int B = 64 * kWaves;                         // threads per block
     // block-shared tables first: their bases (and the row bases below) fit the 16-bit immediate offset of a DS
     // instruction, so an address is just the bit field taken from pk
@@ -502,10 +505,9 @@ __host__ __device__ inline bool reg_kernel_serves(const KParams &kp)
 }
 
 // Phase 1 of a block: fill the block-shared LDS tables (all threads, strided).
-template <int N>
+template <int N, class G = RegGeo<N>>
 __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid)
 {
-    using G = RegGeo<N>;
     constexpr int B = G::B;
     float4 *t_norm = reinterpret_cast<float4 *>(smem + G::oNorm);
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + G::oHist);
@@ -558,10 +560,9 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
 }
 
 // Phase 3 of a block: add the block's histogram to the global one (reference :93-94 summed over the block).
-template <int N>
+template <int N, class G = RegGeo<N>>
 __device__ __forceinline__ void reg_flush_hist(unsigned char *smem, uint32_t tid, unsigned long long *__restrict__ hist)
 {
-    using G = RegGeo<N>;
     const uint32_t *s_hist = reinterpret_cast<const uint32_t *>(smem + G::oHist);
     for (uint32_t i = tid; i < (uint32_t)(N * N); i += G::B) {
         const uint32_t c = s_hist[i];
@@ -583,7 +584,7 @@ constexpr uint32_t kTicketChunks = 0xFFFFFFFFu;      // reg_simulate: "claim chu
 // word 3 | kCompanion); Bernoulli tests compare 53-bit numerators with 53-bit thresholds, normals are binary64
 // (normal53, race_common.hip.h; `norm53` = its table in device memory).  The oracle's PHILOX53 back-end is the same
 // arithmetic.  A priced option: everything WIDE sits behind `if constexpr`, the default kernel is untouched by it.
-template <int N, bool WIDE = false>
+template <int N, bool WIDE = false, class G = RegGeo<N>>
 __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid,
                                              uint32_t *__restrict__ ticket, uint64_t n_sims,
                                              uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
@@ -592,7 +593,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                              uint32_t ws_first_lane, uint32_t fixed_chunk = kTicketChunks,
                                              const double *__restrict__ norm53 = nullptr)
 {
-    using G = RegGeo<N>;
     constexpr int B = G::B;
     static_assert(MCGP_STEP_BATCH % 4 == 0, "a Philox block serves four consecutive places");
     const uint32_t tid4 = tid * 4u, tid8 = tid * 8u;
@@ -1568,23 +1568,23 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
     reg_flush_hist<N>(smem, threadIdx.x, hist);
 }
 
-// The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): same launch geometry, same phases.
+// The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): same phases, blocks of 8 waves at 2 waves per SIMD.
 template <int N>
-__global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
+__global__ void __launch_bounds__((RegGeo<N, kWideBlockWaves>::B), 2)
 race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                      uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                      uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,
                      uint32_t *__restrict__ ticket, uint32_t *__restrict__ retire_ws, const double *__restrict__ norm53)
 {
+    using G = RegGeo<N, kWideBlockWaves>;
     extern __shared__ __align__(16) unsigned char smem[];
-    if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) __builtin_trap();
-    reg_load_tables<N>(P, smem, threadIdx.x);
+    if ((int)blockDim.x != G::B || lds_base_of(smem) != 0u) __builtin_trap();
+    reg_load_tables<N, G>(P, smem, threadIdx.x);
     __syncthreads();
-    reg_simulate<N, true>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
-                          retire_ws, (uint32_t)(gridDim.x * RegGeo<N>::B), (uint32_t)(blockIdx.x * RegGeo<N>::B),
-                          kTicketChunks, norm53);
+    reg_simulate<N, true, G>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
+                             retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B), kTicketChunks, norm53);
     __syncthreads();
-    reg_flush_hist<N>(smem, threadIdx.x, hist);
+    reg_flush_hist<N, G>(smem, threadIdx.x, hist);
 }
 
 // ---- several problems in one launch (mcgp_run_batch) ----
