@@ -454,7 +454,7 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #endif
 
 // A lower bound of every lap time of the problem, lap 1 included (reference :317-332, :301-306), from the inputs alone:
-// slowest possible fuel effect, DRS gain, the largest negative noise the deviate table can give (|z| < 6.5), the most
+// slowest possible fuel effect, DRS gain, the largest negative noise a deviate can give (|z| < 6.5, 8.5 at reference width), the most
 // negative compound delta and degradation x age, the dirty-air penalty if it is negative, the largest start gain.
 // The register kernel relies on times that stay clear of zero: with every lap adding at least kRegTimeFloor seconds
 // and an overtake pass taking at most 0.1 s per pair off a car's time (19 pairs x 3 passes < 6 s per lap), a running
@@ -463,7 +463,8 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 constexpr double kRegTimeFloor = 8.0;
 __host__ __device__ inline double reg_time_floor(const KParams &kp)
 {
-    const double z_max = 6.5;
+    // largest |deviate| a draw can give: Phi^-1(2^-33) = -6.4 from the 32-bit table, Phi^-1(2^-54) = -8.3 at reference width
+    const double z_max = kp.wide ? 8.5 : 6.5;
     double floor_ = __builtin_inf();
     double cdelta_min = __builtin_inf();
     for (int c = 0; c < 5; ++c) cdelta_min = kp.comp_delta[c] < cdelta_min ? kp.comp_delta[c] : cdelta_min;

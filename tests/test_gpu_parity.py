@@ -457,3 +457,24 @@ def test_reference_width_deviates_are_built_for_three_field_sizes(require_gpu):
     with pytest.raises(ValueError):
         RaceSimulator(RaceConfig(**case['config']), deviates=64).run_monte_carlo(
             10, case['grid_probs'], case['base_pace'], case['tire_deg'], case['driver_variance'])
+
+
+def test_lap_times_near_zero_run_on_the_generic_kernel(require_gpu):
+    """reg_kernel_serves: the register kernel marks a retirement in the sign of a last-lap time and drops the reference's
+    max(0.1, ahead - 0.1) (:528), both of which want lap times safely above zero (reg_time_floor >= 8 s).  A field lapping
+    in about 5 s cannot promise that: it runs on the generic kernel, with the oracle's results -- times around 0.1 s, where
+    the max() matters, included."""
+    import copy
+    from monte_carlo_gp_amd import _native as N
+    case = copy.deepcopy(O.load_case('S60'))
+    case['base_pace'] = {d: 5.0 + 0.1 * i for i, d in enumerate(case['base_pace'])}
+    ref = O.Problem(case).run(2000, rng=O.RNG_PHILOX, seed=11, want_orders=True)
+    hist, _, orders = product_run(case, 2000, 11, orders=True)
+    assert N.lib().mcgp_last_kernel_name(0).decode() == 'mcgp::race_kernel'
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+    # 20 s laps are fine for the register kernel (floor 9.5 s)
+    case['base_pace'] = {d: 20.0 + 0.1 * i for i, d in enumerate(case['base_pace'])}
+    ref = O.Problem(case).run(2000, rng=O.RNG_PHILOX, seed=11, want_orders=True)
+    hist, _, orders = product_run(case, 2000, 11, orders=True)
+    assert N.lib().mcgp_last_kernel_name(0).decode() == 'mcgp::race_kernel_reg<20>'
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])

@@ -144,3 +144,20 @@ def test_reference_width_deviates_match_the_oracle(name):
     bad = np.nonzero((orders != ref['orders']).any(axis=1))[0]
     assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
     assert np.array_equal(hist, ref['hist'])
+
+
+def test_register_kernel_domain():
+    """reg_kernel_serves: lap times that are not safely positive (reg_time_floor < 8 s) and a negative overtake_delta are
+    the generic kernel's; 20-second laps are served, with the oracle's results."""
+    import copy
+    case = copy.deepcopy(O.load_case('S60'))
+    case['base_pace'] = {d: 5.0 + 0.1 * i for i, d in enumerate(case['base_pace'])}
+    with pytest.raises(K.NotServed):
+        K.run(case, 10, 1)
+    case['base_pace'] = {d: 20.0 + 0.1 * i for i, d in enumerate(case['base_pace'])}
+    ref = O.Problem(case).run(300, rng=O.RNG_PHILOX, seed=11, want_orders=True)
+    hist, orders = K.run(case, 300, 11)
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+    case['config']['overtake_delta'] = -0.5
+    with pytest.raises(K.NotServed):
+        K.run(case, 10, 1)
