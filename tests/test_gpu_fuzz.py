@@ -42,3 +42,47 @@ def test_fuzzed_configurations_match_oracle(require_gpu, monkeypatch):
     # the generic LDS kernel on every third configuration
     monkeypatch.setenv('MCGP_FORCE_GENERIC', '1')
     assert _check(cases, names[::3], 1000) == {'mcgp::race_kernel'}
+
+
+def test_fuzzed_configurations_at_reference_width(require_gpu):
+    """deviates = 53 against the oracle's PHILOX53 back-end on every fuzz configuration of a field size the wide build
+    exists for (10, 20, 21 cars: 34 configurations, the corner cases among them -- everybody retiring, events on
+    every lap, a pit stop every lap, one-lap races)."""
+    from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N
+    with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
+        cases = json.load(f)
+    done = 0
+    for name, c in cases.items():
+        if len(c['grid_probs']) not in (10, 20, 21) or c['config']['overtake_delta'] < 0:
+            continue
+        ref = O.Problem(c).run(800, rng=O.RNG_PHILOX53, seed=c['seed'], want_orders=True)
+        sim = RaceSimulator(RaceConfig(**c['config']), set_pop=O.load_cases()['set_pop'], deviates=53)
+        _, orders = sim.run_monte_carlo(800, c['grid_probs'], c['base_pace'], c['tire_deg'], c['driver_variance'],
+                                        c.get('driver_dnf_rates'), seed=c['seed'], track_condition=c['track_condition'],
+                                        return_orders=True)
+        assert N.lib().mcgp_last_kernel_name(0).decode().startswith('mcgp::race_kernel_reg_wide<'), name
+        bad = np.nonzero((orders != ref['orders']).any(axis=1))[0]
+        assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
+        assert np.array_equal(sim.last_histogram, ref['hist']), name
+        done += 1
+    assert done >= 30
+
+
+def test_fuzzed_configurations_in_one_batch_launch(require_gpu):
+    """mcgp_run_batch on the 24 twenty-car fuzz configurations the register kernel takes, in ONE launch: every
+    problem's histogram is the oracle's (different circuits, lap counts from 1 to 78, tyre tables, weather, retirement
+    rates up to certainty side by side in one grid of blocks)."""
+    from monte_carlo_gp_amd import RaceConfig, run_monte_carlo_batch
+    with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
+        cases = json.load(f)
+    names = [k for k, c in cases.items() if len(c['grid_probs']) == 20 and c['config']['overtake_delta'] >= 0]
+    assert len(names) >= 24
+    n_sims = 1500
+    problems = [dict(config=RaceConfig(**cases[k]['config']), grid_probs=cases[k]['grid_probs'], base_pace=cases[k]['base_pace'],
+                     tire_deg=cases[k]['tire_deg'], driver_variance=cases[k]['driver_variance'],
+                     driver_dnf_rates=cases[k].get('driver_dnf_rates'), seed=cases[k]['seed'],
+                     track_condition=cases[k]['track_condition'], sim_offset=7 * i) for i, k in enumerate(names)]
+    out = run_monte_carlo_batch(problems, n_sims, set_pop=O.load_cases()['set_pop'])
+    for i, (k, (_, hist)) in enumerate(zip(names, out)):
+        ref = O.Problem(cases[k]).run(n_sims, rng=O.RNG_PHILOX, seed=cases[k]['seed'], sim_offset=7 * i)['hist']
+        assert np.array_equal(hist, ref), k

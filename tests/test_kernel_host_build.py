@@ -161,3 +161,19 @@ def test_register_kernel_domain():
     case['config']['overtake_delta'] = -0.5
     with pytest.raises(K.NotServed):
         K.run(case, 10, 1)
+
+
+def test_fuzzed_configurations_at_reference_width():
+    """The host build of reg_simulate<N, true> against the oracle's PHILOX53 back-end on the fuzz configurations of 10, 20
+    and 21 cars (the GPU run of the same comparison: tests/test_gpu_fuzz.py)."""
+    with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
+        cases = json.load(f)
+    done = 0
+    for name, c in cases.items():
+        if len(c['grid_probs']) not in (10, 20, 21) or c['config']['overtake_delta'] < 0:
+            continue
+        ref = O.Problem(c).run(200, rng=O.RNG_PHILOX53, seed=c['seed'], want_orders=True)
+        hist, orders = K.run(c, 200, c['seed'], deviates=53)
+        assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist']), name
+        done += 1
+    assert done >= 30
