@@ -478,3 +478,20 @@ def test_lap_times_near_zero_run_on_the_generic_kernel(require_gpu):
     hist, _, orders = product_run(case, 2000, 11, orders=True)
     assert N.lib().mcgp_last_kernel_name(0).decode() == 'mcgp::race_kernel_reg<20>'
     assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+
+
+def test_thousand_lap_race(require_gpu):
+    """MCGP_MAX_LAPS: the retirement keys (lap << 5 | driver, 15 bits) and the age field of pk at their largest, in both
+    deviate widths."""
+    import copy
+    from monte_carlo_gp_amd import RaceConfig, RaceSimulator
+    case = copy.deepcopy(O.load_case('N10'))
+    case['config']['total_laps'] = 1000
+    case['driver_dnf_rates'] = {d: 0.002 for d in case['base_pace']}          # most cars out somewhere in 1000 laps
+    for deviates, rng in ((32, O.RNG_PHILOX), (53, O.RNG_PHILOX53)):
+        ref = O.Problem(case).run(200, rng=rng, seed=3, want_orders=True)
+        sim = RaceSimulator(RaceConfig(**case['config']), set_pop=O.load_cases()['set_pop'], deviates=deviates)
+        _, orders = sim.run_monte_carlo(200, case['grid_probs'], case['base_pace'], case['tire_deg'], case['driver_variance'],
+                                        case['driver_dnf_rates'], seed=3, track_condition=case['track_condition'],
+                                        return_orders=True)
+        assert np.array_equal(orders, ref['orders']) and np.array_equal(sim.last_histogram, ref['hist']), deviates

@@ -177,3 +177,14 @@ def test_fuzzed_configurations_at_reference_width():
         assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist']), name
         done += 1
     assert done >= 30
+
+
+def test_thousand_lap_race():
+    """MCGP_MAX_LAPS: the retirement keys (lap << 5 | driver, 15 bits) and the age field of pk at their largest."""
+    import copy
+    case = copy.deepcopy(O.load_case('N10'))
+    case['config']['total_laps'] = 1000
+    case['driver_dnf_rates'] = {d: 0.002 for d in case['base_pace']}          # most cars out somewhere in 1000 laps
+    ref = O.Problem(case).run(24, rng=O.RNG_PHILOX, seed=3, want_orders=True)
+    hist, orders = K.run(case, 24, 3)
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
