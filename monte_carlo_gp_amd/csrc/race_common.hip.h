@@ -109,22 +109,32 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // One 32-bit word -> N(0,1): piecewise-cubic inverse CDF (tools/gen_normal_table.py).  `row(k)` returns the
 // k-th coefficient row as a float4.
-template <typename RowFn>
-__device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
+// (in two steps, so that a caller with several deviates to make can fetch all their rows before evaluating any)
+__device__ __forceinline__ void normal_prepare(uint32_t w, uint32_t &row, float &t)
 {
     // m + 16 has its leading one in bit 4 .. 31: c = clz picks the octave, the next four bits the cell, the rest is the
     // offset inside the cell -- no special case for the smallest m, no select (tools/gen_normal_table.py)
     const uint32_t mm = (w & 0x7fffffffu) + 16u;
     const uint32_t c = (uint32_t)__clz((int)mm);
     const uint32_t x = mm << c;
-    const uint32_t row = 16u * c + ((x >> 27) & 15u);
-    const float t = (float)(((x & 0x07ffffffu) << 1) | (1u << c));          // cell coordinate x 2^28
-    const float4 cf = row_of(row);
+    row = 16u * c + ((x >> 27) & 15u);
+    t = (float)(((x & 0x07ffffffu) << 1) | (1u << c));                      // cell coordinate x 2^28
+}
+__device__ __forceinline__ float normal_evaluate(uint32_t w, const float4 cf, float t)
+{
     float z = __builtin_fmaf(cf.w, t, cf.z);
     z = __builtin_fmaf(z, t, cf.y);
     z = __builtin_fmaf(z, t, cf.x);
     // z0 = Phi^-1(tail probability) is negative (or -0): the sign bit of w flips it
     return __uint_as_float(__float_as_uint(z) ^ (w & 0x80000000u));
+}
+template <typename RowFn>
+__device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
+{
+    uint32_t row;
+    float t;
+    normal_prepare(w, row, t);
+    return normal_evaluate(w, row_of(row), t);
 }
 
 // Reference-width normal: z0 = Phi^-1((q + 0.5) / 2^53) < 0 for the 52-bit tail index q, degree-7 polynomial on

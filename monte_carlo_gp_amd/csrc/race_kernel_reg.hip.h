@@ -64,21 +64,26 @@
 
 namespace mcgp {
 
-// pk word of the register kernel.  Field positions are chosen so that LDS addresses fall out of one
-// mask or one shift + mask: (pk >> 6) & 0x1F0 = 16 driver; (pk >> 6) & 0x3F0 = 16 (32 dnf + driver);
-// (pk & 0x380) << 2 = 512 compound; (pk >> 3) & 0x70 = 16 compound; pk & 0x10 = 16 drs; and
-// (pk & k3AgeMask) + (1 << 16) = (tyre age + 1) << 16, which compares directly with the pit-stop word.
+// pk word of the register kernel.  Field positions are chosen so that LDS addresses fall out of ONE mask wherever a
+// table is indexed three times a lap (the overtake passes) and of a shift + mask elsewhere:  pk & 0x1F0 = 16 driver;
+// pk & 0x3F0 = 16 (32 dnf + driver);  pk & 8 = 8 drs;  (pk & 0x1C00) >> 1 = 512 compound;  (pk >> 6) & 0x70 = 16 compound;
+// and (pk & k3AgeMask) + (1 << 16) = (tyre age + 1) << 16, which compares directly with the pit-stop word.
 constexpr uint32_t k3UsedMask = 7u;            // [0..2] dry compounds used so far (SOFT, MEDIUM, HARD)
-constexpr uint32_t k3Drs = 1u << 4;            // (pk & 0x10) = 16 drs: byte offset into the {0.0, drs_delta} table
-constexpr uint32_t k3Dirty = 1u << 5;          // 0 < time_behind_leader < dirty_air_threshold
-constexpr int k3CompShift = 7;                 // [7..9]   tyre compound
-constexpr uint32_t k3CompMask = 7u << k3CompShift;
-constexpr int k3IdShift = 10;                  // [10..14] driver index
+constexpr uint32_t k3Drs = 1u << 3;            // (pk & 8) = 8 drs: byte offset into the {0.0, drs_delta} table
+constexpr int k3IdShift = 4;                   // [4..8] driver index: (pk & k3IdMask) = 16 driver
 constexpr uint32_t k3IdMask = 31u << k3IdShift;
-constexpr uint32_t k3Dnf = 1u << 15;           // directly above the driver index: (pk >> 6) & 0x3F0 = 16 (32 dnf + driver)
+constexpr uint32_t k3Dnf = 1u << 9;            // directly above the driver index: pk & k3SlotMask = 16 (32 dnf + driver)
+constexpr uint32_t k3SlotMask = k3IdMask | k3Dnf;
+constexpr int k3CompShift = 10;                // [10..12] tyre compound
+constexpr uint32_t k3CompMask = 7u << k3CompShift;
+constexpr uint32_t k3Dirty = 1u << 13;         // 0 < time_behind_leader < dirty_air_threshold   ([14..15] unused)
 constexpr int k3AgeShift = 16;                 // [16..26] tyre age; lap of retirement once dnf is set
 constexpr uint32_t k3AgeMask = 0x7FFu << k3AgeShift;
 constexpr int k3GposShift = 27;                // [27..31] grid slot (most significant: tie-break)
+__host__ __device__ constexpr uint32_t pk_driver16(uint32_t p) { return p & k3IdMask; }                  // 16 x driver
+__host__ __device__ constexpr uint32_t pk_slot16(uint32_t p) { return p & k3SlotMask; }                  // 16 x (32 dnf + driver)
+__host__ __device__ constexpr uint32_t pk_comp512(uint32_t p) { return (p & k3CompMask) >> (k3CompShift - 9); }   // 512 x compound
+__host__ __device__ constexpr uint32_t pk_comp16(uint32_t p) { return (p >> (k3CompShift - 4)) & 0x70u; }        // 16 x compound
 constexpr double kAgeFieldUnit = 1.0 / 65536.0;   // tables that multiply (pk & k3AgeMask) carry this factor
 
 // ---- launch geometry and LDS map, fixed per field size ----
@@ -152,8 +157,8 @@ struct RegGeo {
     static constexpr uint32_t oDrvB = oDrvA + N * 16;             // {base, deg} 2^31 x N drivers; at +32 entries {NaN, NaN} x N  (overtake pace)
     static constexpr uint32_t oIc = oDrvB + (kMaxCars + N) * 16;  // [compound][driver] {eff f64, pit word u32, DNF threshold u32}
     static constexpr uint32_t oComp = oIc + ((kNumCompounds - 1) * kMaxCars + N) * 16;   // {delta f64, pad} x 8, 16 B each
-    static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, pad}, {drs_delta, pad}              (lap time)
-    static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, pad}, {drs_delta 2^31, pad}         (overtake pace)
+    static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, drs_delta}                          (lap time)
+    static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, drs_delta 2^31}                     (overtake pace)
     static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
     static constexpr uint32_t oHist = oLut + 128;                 // u32[N x N]
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
@@ -351,7 +356,7 @@ __device__ __forceinline__ bool ties_in_order(const double (&cum)[N], const uint
 // almost never have anything to do (the structural ties of the reference, lap-1 retirements at 0.0, are
 // kept apart by the representation chosen in lap 1, see there).
 template <int N>
-__device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N])
+__device__ __forceinline__ bool network_sort(double (&cum)[N], uint32_t (&pk)[N])
 {
     constexpr MergeExchange<N> net{};
     network_sort_impl<N>(cum, pk, std::make_index_sequence<(size_t)net.n_groups>{});
@@ -360,6 +365,7 @@ __device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N]
     if (__builtin_expect(!strict, 0)) {
         if (!ties_in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
     }
+    return strict;                                 // no two equal times in the field (update_positions_reg)
 }
 
 // Re-sort after an overtake pass.  The pass moved a few cars: the overtaken one back by 0.2 s, the
@@ -369,7 +375,7 @@ __device__ __forceinline__ void network_sort(double (&cum)[N], uint32_t (&pk)[N]
 // The result is then CHECKED with the full (time, grid slot) order and anything left -- cars crossing
 // each other, a new exact tie in the wrong grid order -- goes to the general re-sort.
 template <int N>
-__device__ __forceinline__ void resort_after_overtakes(double (&cum)[N], uint32_t (&pk)[N])
+__device__ __forceinline__ bool resort_after_overtakes(double (&cum)[N], uint32_t (&pk)[N])
 {
 #if MCGP_RESORT_ROUNDS
     // experiment: odd-even transposition rounds (independent comparators within a round) instead of the two bubble passes
@@ -390,11 +396,15 @@ __device__ __forceinline__ void resort_after_overtakes(double (&cum)[N], uint32_
     if (__builtin_expect(!strict, 0)) {
         if (!in_order<N>(cum, pk)) transposition_sort<N>(cum, pk);
     }
+    return strict;
 }
 
 // _update_positions, reference :538-560: gap to the leader (kept as the dirty-air flag, :209-212) and the DRS flag
 // of every running car, in rank order; retired cars are skipped.
-template <int N>
+// DISTINCT: the caller knows that no two times of the field are equal (the sorts report it; all but a few wave-laps
+// in a hundred).  Every car behind the leader then has a gap > 0 and the first half of :552's  0 < gap < threshold
+// is the "not the first running car" mask the DRS flag needs anyway: one binary64 compare less per slot.
+template <int N, bool DISTINCT = false>
 __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uint32_t (&pk)[N],
                                                      bool drs_allowed, double dirty_thr)
 {
@@ -411,7 +421,7 @@ __device__ __forceinline__ void update_positions_reg(const double (&cum)[N], uin
         const double t = cum[i];
         leader = (act && first) ? t : leader;
         const double tbl = t - leader;                                               // :551
-        const bool dirty = tbl > 0 && tbl < dirty_thr;
+        const bool dirty = (DISTINCT ? !first : tbl > 0) && tbl < dirty_thr;
         const bool drs = !first && drs_allowed && (t - prev) < 1.0;                  // :553-558
         pk[i] = (p & ~(k3Drs | k3Dirty)) | (dirty ? k3Dirty : 0u) | (drs ? k3Drs : 0u);
         prev = act ? t : prev;
@@ -448,6 +458,9 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #endif
 #ifndef MCGP_STEP_BATCH
 #define MCGP_STEP_BATCH 4          // slots whose LDS gathers (and Philox blocks) are in flight together in the lap step
+#endif
+#ifndef MCGP_DISTINCT_PATH
+#define MCGP_DISTINCT_PATH 1       // update_positions_reg<N, true> for the wave-laps whose fields have no equal times
 #endif
 #ifndef MCGP_PACE_BATCH
 #define MCGP_PACE_BATCH 5          // slots whose pace gathers are in flight together in an overtake pass (10: same speed, 52 B of spills against 20)
@@ -529,12 +542,9 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         b[2 * kMaxCars + 1] = qnan;
     }
     if (tid < 2) {
-        double *r = reinterpret_cast<double *>(smem + G::oDrs + tid * 16);
-        r[0] = tid ? P->drs_delta : 0.0;
-        r[1] = 0.0;
-        double *q = reinterpret_cast<double *>(smem + G::oDrsB + tid * 16);
-        q[0] = tid ? P->drs_delta * 2147483648.0 : 0.0;
-        q[1] = 0.0;
+        // {0.0, drs_delta}: a car's row is at byte offset (pk & k3Drs)
+        *reinterpret_cast<double *>(smem + G::oDrs + tid * k3Drs) = tid ? P->drs_delta : 0.0;
+        *reinterpret_cast<double *>(smem + G::oDrsB + tid * k3Drs) = tid ? P->drs_delta * 2147483648.0 : 0.0;
     }
     for (uint32_t i = tid; i < (uint32_t)kNumCompounds * N; i += B) {
         const uint32_t c = i / N, d = i % N;
@@ -626,16 +636,16 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     auto load_slot = [&](uint32_t p, uint32_t lut_base) -> SlotIn {
         SlotIn r;
         r.fit = lds_ld<uint32_t>(((p & k3UsedMask) << 2) + lut_base);
-        const uint32_t id16 = (p >> 6) & 0x1F0u;                                  // 16 x driver
+        const uint32_t id16 = pk_driver16(p);                                     // 16 x driver
         r.la = id16 * (uint32_t)(B / 2) + tid8;                                   // = driver x (B x 8) + tid8
         r.last = lds_ld<double>(G::oLast + r.la);
-        const uint32_t ic = id16 + ((p & k3CompMask) << 2);                       // 16 x (32 compound + driver)
+        const uint32_t ic = id16 + pk_comp512(p);                                 // 16 x (32 compound + driver)
         const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);
         r.var = vb.x;
         r.base = vb.y;
         uint32_t pad;
         lds_ld_f64_u32x2(G::oIc + ic, r.eff, r.pitw, pad);
-        r.cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));                 // 16 x compound
+        r.cdelta = lds_ld<double>(G::oComp + pk_comp16(p));                        // 16 x compound
         r.drs = lds_ld<double>(G::oDrs + (p & k3Drs));                            // 0.0 or drs_delta
         return r;
     };
@@ -782,10 +792,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             for (int i = 0; i < N; ++i) {
                 const uint32_t p = pk[i];
                 const double z = lds_ld<double>(G::oLast + last_of(p));
-                const uint32_t id16 = (p >> 6) & 0x1F0u;
+                const uint32_t id16 = pk_driver16(p);
                 const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);                        // {variance, base pace}
-                const double eff = lds_ld<double>(G::oIc + id16 + ((p & k3CompMask) << 2));
-                const double cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));
+                const double eff = lds_ld<double>(G::oIc + id16 + pk_comp512(p));
+                const double cdelta = lds_ld<double>(G::oComp + pk_comp16(p));
                 if (z != z) {
                     pk[i] = (p & ~k3AgeMask) | k3Dnf | (1u << k3AgeShift);
                     cum[i] = -(double)(i + 1) * 0x1p-1000;                              // (see the default path below)
@@ -833,10 +843,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const uint32_t la = last_of(p);
                 const float z = lds_ld<float>(G::oLast + la);
                 const double zs = (double)lds_ld<float>(G::oLast + la + 4u);
-                const uint32_t id16 = (p >> 6) & 0x1F0u;
+                const uint32_t id16 = pk_driver16(p);
                 const f64x2 vb = lds_ld_f64x2(G::oDrvA + id16);                        // {variance, base pace}
-                const double eff = lds_ld<double>(G::oIc + id16 + ((p & k3CompMask) << 2));
-                const double cdelta = lds_ld<double>(G::oComp + ((p >> 3) & 0x70u));
+                const double eff = lds_ld<double>(G::oIc + id16 + pk_comp512(p));
+                const double cdelta = lds_ld<double>(G::oComp + pk_comp16(p));
                 if (z != z) {
                     pk[i] = (p & ~k3AgeMask) | k3Dnf | (1u << k3AgeShift);
                     // The reference leaves a lap-1 retirement at cumulative_time 0.0, so several of them tie; ties sort
@@ -1004,7 +1014,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             // eight 64-bit values that would otherwise push as many lane masks and addresses out to scratch.
             const KParams *Pl = P;
             pin_ptr(Pl);
-            const double pit_loss = Pl->pit_loss, od31 = Pl->overtake_delta_31, dirty_thr = Pl->dirty_thr, dirty_pen = Pl->dirty_pen;
+            const double pit_loss = Pl->pit_loss, od31 = Pl->overtake_delta_31, dirty_thr = Pl->dirty_thr;
+            const double dirty_pen_lap = lap == 2 ? 0.0 : Pl->dirty_pen;         // (no dirty-air constraint in lap 2: see the lap step)
             const uint64_t t_red = WIDE ? Pl->t53_red : Pl->t_red, t_sc = WIDE ? Pl->t53_sc : Pl->t_sc,
                            t_vsc = WIDE ? Pl->t53_vsc : Pl->t_vsc, t_vsc_tire = WIDE ? Pl->t53_vsc_tire : Pl->t_vsc_tire;
             // ---- race-interrupting events, :168-176 ----
@@ -1247,10 +1258,26 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     // the lap-noise deviate: binary32 from the cubic table, or (WIDE) binary64 from the degree-7 table
                     using Deviate = std::conditional_t<WIDE, double, float>;
                     Deviate z[MCGP_STEP_BATCH];
+                    if constexpr (WIDE) {
 #pragma unroll
-                    for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
-                        if constexpr (WIDE) z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
-                        else z[j] = (i0 + j < N) ? normal_from_u32_rows(w[j >> 2][j & 3], norm_row) : 0.0f;
+                        for (int j = 0; j < MCGP_STEP_BATCH; ++j)
+                            z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
+                    } else {
+                        // two table rows are fetched at a time, then evaluated (half the LDS round trips in a row; four at a
+                        // time cost sixteen registers the loop does not have)
+#pragma unroll
+                        for (int j0 = 0; j0 < MCGP_STEP_BATCH; j0 += 2) {
+                            uint32_t zrow[2];
+                            float zt[2];
+                            float4 zc[2];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) normal_prepare(w[(j0 + j) >> 2][(j0 + j) & 3], zrow[j], zt[j]);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) zc[j] = norm_row(zrow[j]);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                z[j0 + j] = (i0 + j0 + j < N) ? normal_evaluate(w[(j0 + j) >> 2][(j0 + j) & 3], zc[j], zt[j]) : 0.0f;
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
@@ -1267,12 +1294,25 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const uint32_t agef = p & k3AgeMask;
                         const double tire = (double)agef * s.eff;                                   // :319-322 (eff x 2^-16)
                         const double drs_gain = s.drs;                                              // :327
-                        const double noise = 0.0 + s.var * (double)z[j];                            // :330
+                        // :330.  np.random.normal(0, sigma) is 0.0 + sigma z: the addition only turns a -0.0 product into +0.0,
+                        // which the sum below cannot tell apart unless its other terms cancel exactly -- a lap time of pure
+                        // noise, which reg_time_floor() keeps out of this kernel
+                        const double noise = s.var * (double)z[j];
                         const double clean = s.base + tire - fuel_effect + s.cdelta - drs_gain + noise;   // :332
-                        const double dirty_time = clean + dirty_pen;                                // :213
-                        const double held = max_abs_f64(ahead_last, dirty_time);                    // :215 (neither is NaN)
-                        const bool in_dirty = (p & k3Dirty) && fabs(ahead_last) > 0;                // :209-212
-                        const double lap_time = in_dirty ? held : clean;
+                        // :207-215, without a select.  A car flagged dirty is not the first running car (its gap to the
+                        // leader is > 0: _update_positions and every event handler keep flag and order consistent), and from lap
+                        // 3 on the running car ahead of it has driven the lap before, so its last lap time is a lap time: > 0
+                        // (reg_time_floor), and :211's  car_ahead_lap > 0  is the flag itself.  In lap 2 no car has a last lap
+                        // time yet (lap 1 does not record one, :219 is the only writer) and the constraint is off for everybody:
+                        // that lap runs with a penalty of +0.0 and, ahead = 0, a maximum that returns the clean time.
+                        // Masked by the flag, both terms of :213-215 vanish for a clean-air car:  max(|0|, clean + 0.0) = clean
+                        // (clean > 0).
+                        const uint32_t dirty_m = (uint32_t)((int32_t)(p << (31 - 13)) >> 31);                  // all ones iff k3Dirty
+                        const double pen_if_dirty = __hiloint2double((int)((uint32_t)__double2hiint(dirty_pen_lap) & dirty_m),
+                                                                     (int)((uint32_t)__double2loint(dirty_pen_lap) & dirty_m));
+                        const double ahead_if_dirty = __hiloint2double((int)((uint32_t)__double2hiint(ahead_last) & dirty_m),
+                                                                       (int)((uint32_t)__double2loint(ahead_last) & dirty_m));
+                        const double lap_time = max_abs_f64(ahead_if_dirty, clean + pen_if_dirty);          // :213, :215 (neither is NaN)
                         // pit stop (:450-492): (tyre age + 1) << 16 against the pit word; compound and used-set from
                         // the rule table (pit_rule_word)
                         const bool pit = run && pit_window && (agef + (1u << k3AgeShift)) > s.pitw;
@@ -1293,7 +1333,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             }
 
             // ---- _simulate_overtakes, :496-536 ----
-            if (!(MCGP_SKIP & 16)) network_sort<N>(cum, pk);
+            bool distinct_times = true;
+            if (!(MCGP_SKIP & 16)) distinct_times = network_sort<N>(cum, pk);
             if (MCGP_DUP & 1) network_sort<N>(cum, pk);
             // The three passes are three copies of the code: a rolled loop makes the compiler shuffle the whole field
             // (60 registers, renamed by every compare-exchange) back into place at its back edge; unrolled it is 3-4 %
@@ -1319,7 +1360,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         double pace_prev = 0.0;
 #pragma unroll
                         for (int i = 0; i < N; ++i) {
-                            const f64x2 bd = lds_ld_f64x2(G::oDrvB + ((pk[i] >> 6) & 0x3F0u));
+                            const f64x2 bd = lds_ld_f64x2(G::oDrvB + pk_slot16(pk[i]));
                             const double pace = bd.x + (double)(pk[i] & k3AgeMask) * bd.y;
                             thr64[i] = 0ull;
                             if (i > 0) {
@@ -1400,7 +1441,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll
                             for (int j = 0; j < H; ++j) {
                                 if (h + j < N) {
-                                    const uint32_t id16 = (pk[h + j] >> 6) & 0x3F0u;      // 16 x (32 dnf + driver)
+                                    const uint32_t id16 = pk_slot16(pk[h + j]);           // 16 x (32 dnf + driver)
                                     const f64x2 bd = lds_ld_f64x2(G::oDrvB + id16);
                                     pb[j] = bd.x;
                                     pd[j] = bd.y;
@@ -1495,11 +1536,16 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 (void)n_attempts;
                 if (!any_succ) break;
                 // ---- overtakes: re-sort ----
-                resort_after_overtakes<N>(cum, pk);     // sorted again for the next pass / _update_positions
+                distinct_times = resort_after_overtakes<N>(cum, pk);     // sorted again for the next pass / _update_positions
                 if (MCGP_DUP & 8) resort_after_overtakes<N>(cum, pk);
             }
             // ---- _update_positions, :227-228 ----
-            if (!(MCGP_SKIP & 32)) update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
+            if (!(MCGP_SKIP & 32)) {
+                if (MCGP_DISTINCT_PATH && !MCGP_ANY(!distinct_times))
+                    update_positions_reg<N, true>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
+                else
+                    update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
+            }
             if (MCGP_DUP & 4) update_positions_reg<N>(cum, pk, lap > 2 && lap > drs_disabled_until, dirty_thr);
         }
 

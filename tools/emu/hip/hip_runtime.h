@@ -44,6 +44,12 @@ inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b)
 {
     return (unsigned long long)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
 }
+inline int __double2loint(double x)
+{
+    uint64_t u;
+    std::memcpy(&u, &x, 8);
+    return (int)(uint32_t)u;
+}
 inline int __double2hiint(double x)
 {
     uint64_t u;
