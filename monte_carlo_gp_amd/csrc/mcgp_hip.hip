@@ -935,7 +935,7 @@ int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)c->lds_per_block));
-        // geometry: the register kernel's block, one more LDS word for the task hand-over
+        // geometry: the register kernel's block, one more LDS word that names the block's next problem
         const int waves = mcgp::reg_block_waves((int)n);
         const uint32_t block = (uint32_t)waves * 64u;
         const size_t lds = mcgp::shared_lds_bytes_reg((int)n) + (size_t)block * mcgp::per_thread_lds_bytes_reg((int)n) +
@@ -945,16 +945,17 @@ int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_
         if (blocks_per_cu * waves > reg_cap) blocks_per_cu = reg_cap / waves;
         if (blocks_per_cu < 1) blocks_per_cu = 1;
         const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
-        const uint64_t n_tasks = (uint64_t)n_problems * ((n_chunks + (uint32_t)waves - 1) / (uint32_t)waves);
-        if (n_tasks >= 0xFFFF0000ull) return fail(MCGP_E_BAD_ARG, "batch too large for one launch");
+        // no more blocks than the batch has wave-chunks to fill them with
+        const uint64_t n_tasks = ((uint64_t)n_problems * n_chunks + (uint64_t)waves - 1) / (uint64_t)waves;
         uint64_t grid = (uint64_t)c->cu_count * (uint64_t)blocks_per_cu;
         if (grid > n_tasks) grid = n_tasks;
-        // one device buffer: [parameter blocks | items | histograms | ticket]
+        // one device buffer: [parameter blocks | items | histograms | one ticket counter per problem]
         const size_t o_items = sizeof(mcgp::KParams) * n_problems;
         const size_t o_hist = o_items + sizeof(mcgp::BatchItem) * n_problems;
         const size_t hist_bytes = sizeof(unsigned long long) * n * n * n_problems;
         const size_t o_ticket = o_hist + hist_bytes;
-        const size_t bytes = o_ticket + 16;
+        const size_t ticket_bytes = (sizeof(uint32_t) * n_problems + 15) / 16 * 16;
+        const size_t bytes = o_ticket + ticket_bytes;
         if (bytes > c->batch_bytes) {
             if (c->d_batch) (void)hipFree(c->d_batch);
             c->d_batch = nullptr;
@@ -973,7 +974,7 @@ int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_
         unsigned char *d = c->d_batch;
         HIP_TRY(hipMemcpyAsync(d, kps.data(), o_items, hipMemcpyHostToDevice, nullptr));
         HIP_TRY(hipMemcpyAsync(d + o_items, items.data(), sizeof(mcgp::BatchItem) * n_problems, hipMemcpyHostToDevice, nullptr));
-        HIP_TRY(hipMemsetAsync(d + o_hist, 0, hist_bytes + 16, nullptr));
+        HIP_TRY(hipMemsetAsync(d + o_hist, 0, hist_bytes + ticket_bytes, nullptr));
         // timed like the other launches (the default stream's entry)
         int ti = -1;
         for (int i = 0; i < kStreamTimers; ++i)

@@ -396,6 +396,17 @@ __device__ __forceinline__ uint32_t next_ticket(uint32_t *counter, uint32_t /*ti
         t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
+// a ticket counter's current value, without taking a ticket
+__device__ __forceinline__ uint32_t peek_ticket(const uint32_t *counter)
+{
+    return __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the first lane of the wavefront in which the predicate holds, 64 if there is none (wave-uniform result)
+__device__ __forceinline__ uint32_t first_lane_with(bool pred)
+{
+    const unsigned long long m = __ballot(pred);
+    return m ? (uint32_t)__builtin_ctzll(m) : 64u;
+}
 // true if the predicate holds in ANY lane of the wavefront (wave-uniform result)
 #define MCGP_ANY(pred) (__any((int)(pred)) != 0)
 // Keeps a value computed where it is written: the compiler may not sink its computation into one arm of a later

@@ -581,8 +581,6 @@ __device__ __forceinline__ void reg_flush_hist(unsigned char *smem, uint32_t tid
     }
 }
 
-constexpr uint32_t kTicketChunks = 0xFFFFFFFFu;      // reg_simulate: "claim chunks from the ticket counter"
-
 // Phase 2: the simulations, one full race per lane.  The unit of work is a WAVE-CHUNK of 64 consecutive simulations,
 // and every wave of the launch claims its next chunk from one ticket counter in device memory (zeroed by the host
 // before the launch) until the chunks run out: a wave that runs faster than its neighbours takes more of them instead
@@ -601,8 +599,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                              uint64_t sim_offset, uint32_t seed_lo, uint32_t seed_hi,
                                              uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid,
                                              uint32_t n_chunks, uint32_t *__restrict__ retire_ws_base, uint32_t ws_stride,
-                                             uint32_t ws_first_lane, uint32_t fixed_chunk = kTicketChunks,
-                                             const double *__restrict__ norm53 = nullptr)
+                                             uint32_t ws_first_lane, const double *__restrict__ norm53 = nullptr)
 {
     constexpr int B = G::B;
     static_assert(MCGP_STEP_BATCH % 4 == 0, "a Philox block serves four consecutive places");
@@ -651,9 +648,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     };
 
     for (uint32_t turn = 0u;; ++turn) {
-        // (a batch launch hands every wave ONE chunk of the block's current problem instead: race_kernel_reg_batch)
-        if (fixed_chunk != kTicketChunks && turn > 0u) break;
-        const uint32_t chunk = fixed_chunk != kTicketChunks ? fixed_chunk : next_ticket(ticket, tid, turn, G::kWaves);
+        const uint32_t chunk = next_ticket(ticket, tid, turn, G::kWaves);
         if (chunk >= n_chunks) break;                            // (every wave ends on its first ticket past the end)
         const uint64_t local = (uint64_t)chunk * 64ull + (uint64_t)(tid & 63u);
         // A lane past the end of the run still runs a race while any lane of its wave has one to run -- the wave's
@@ -1629,7 +1624,7 @@ race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t si
     reg_load_tables<N, G>(P, smem, threadIdx.x);
     __syncthreads();
     reg_simulate<N, true, G>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
-                             retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B), kTicketChunks, norm53);
+                             retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B), norm53);
     __syncthreads();
     reg_flush_hist<N, G>(smem, threadIdx.x, hist);
 }
@@ -1637,9 +1632,12 @@ race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t si
 // ---- several problems in one launch (mcgp_run_batch) ----
 // The reference predicts a race from 10 000 simulations (reference src/predictor.py:284) and a backtest runs two dozen
 // races one after the other (src/validation.py:179-185): at that size a launch is as long as ONE race of one lane and the
-// device is mostly idle, so the races of a sweep go into one launch.  The block-shared tables belong to one problem, so
-// the unit of work is a block-task: (problem, group of kWaves consecutive chunks); blocks claim tasks from the launch's
-// ticket counter, reload the tables when the problem changes, and every wave runs the task's chunk that falls to it.
+// device is mostly idle, so the races of a sweep go into one launch.  The block-shared tables belong to one problem, so a
+// BLOCK works on one problem at a time; inside it every WAVE claims chunks from that problem's own ticket counter, as in
+// a single-problem launch, until the problem has none left.  The block then moves on to the next problem (in cyclic order
+// from where it started) that still has chunks to hand out, reloads the tables and goes on; blocks start spread evenly
+// over the problems.  Nothing waits for a whole group of chunks: the second round of a problem whose chunks do not fill
+// its blocks' waves evenly runs on the few waves that come free first, with the SIMDs nearly to themselves.
 // Per-problem inputs that are not in the parameter block:
 struct BatchItem {
     uint64_t sim_offset, seed;
@@ -1648,37 +1646,50 @@ template <int N>
 __global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
 race_kernel_reg_batch(const KParams *__restrict__ P, const BatchItem *__restrict__ items, uint32_t n_problems,
                       uint64_t n_sims, unsigned long long *__restrict__ hist, uint32_t n_chunks,
-                      uint32_t *__restrict__ ticket, uint32_t *__restrict__ retire_ws)
+                      uint32_t *__restrict__ tickets, uint32_t *__restrict__ retire_ws)
 {
     using G = RegGeo<N>;
     extern __shared__ __align__(16) unsigned char smem[];
     if ((int)blockDim.x != G::B || lds_base_of(smem) != 0u) __builtin_trap();
-    const uint32_t groups = (n_chunks + (uint32_t)G::kWaves - 1u) / (uint32_t)G::kWaves;     // block-tasks per problem
-    const uint32_t n_tasks = n_problems * groups;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t cur = 0xFFFFFFFFu;                                  // the problem whose tables are in LDS
+    // first problem of this block; `visited` problems have been looked at (each at most once: the loop ends)
+    uint32_t p = (uint32_t)(((uint64_t)blockIdx.x * n_problems) / gridDim.x);
+    uint32_t visited = 0u;
     for (;;) {
-        // one thread claims the block's next task; the word just past the kernel's LDS map carries it to the others
-        if (threadIdx.x == 0) lds_st<uint32_t>(G::kBytes, atomicAdd(ticket, 1u));
-        __syncthreads();
-        const uint32_t task = lds_ld<uint32_t>(G::kBytes);
-        if (task >= n_tasks) break;
-        const uint32_t p = task / groups, group = task % groups;
-        if (p != cur) {
-            if (cur != 0xFFFFFFFFu) reg_flush_hist<N>(smem, threadIdx.x, hist + (size_t)cur * N * N);
-            __syncthreads();                                     // (flush reads the LDS histogram the table load zeroes)
-            reg_load_tables<N>(P + p, smem, threadIdx.x);
-            __syncthreads();
-            cur = p;
+        // wave 0 looks for the next problem with chunks left, 64 counters at a time, and leaves it (or "none") in the word
+        // just past the kernel's LDS map
+        if (threadIdx.x < 64u) {
+            uint32_t found = 0xFFFFFFFFu, seen = visited;
+            while (seen < n_problems) {
+                const uint32_t k = seen + threadIdx.x;                         // k-th problem after the start, cyclically
+                uint32_t q = p + (k - visited);
+                if (q >= n_problems) q -= n_problems;
+                const uint32_t lane = first_lane_with(k < n_problems && peek_ticket(&tickets[q]) < n_chunks);
+                if (lane < 64u) {
+                    found = seen + lane;
+                    break;
+                }
+                seen += 64u;
+            }
+            if (threadIdx.x == 0u) lds_st<uint32_t>(G::kBytes, found);
         }
+        __syncthreads();
+        const uint32_t found = lds_ld<uint32_t>(G::kBytes);
+        if (found == 0xFFFFFFFFu) break;
+        p += found - visited;
+        if (p >= n_problems) p -= n_problems;
+        visited = found + 1u;
+        reg_load_tables<N>(P + p, smem, threadIdx.x);            // (zeroes the LDS histogram)
+        __syncthreads();
         const BatchItem it = items[p];
-        reg_simulate<N>(P + p, smem, threadIdx.x, nullptr, n_sims, it.sim_offset, (uint32_t)it.seed, (uint32_t)(it.seed >> 32),
-                        nullptr, nullptr, n_chunks, retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B),
-                        group * (uint32_t)G::kWaves + wave);
-        __syncthreads();                                         // every wave's counts are in before a flush or a reload
+        reg_simulate<N>(P + p, smem, threadIdx.x, tickets + p, n_sims, it.sim_offset, (uint32_t)it.seed, (uint32_t)(it.seed >> 32),
+                        nullptr, nullptr, n_chunks, retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B));
+        __syncthreads();                                         // every wave's counts are in
+        reg_flush_hist<N>(smem, threadIdx.x, hist + (size_t)p * N * N);
+        __syncthreads();                                         // (the flush reads what the next table load zeroes)
+        p += 1u;
+        if (p >= n_problems) p -= n_problems;
     }
-    if (cur != 0xFFFFFFFFu) reg_flush_hist<N>(smem, threadIdx.x, hist + (size_t)cur * N * N);
 }
-constexpr size_t kBatchLdsExtra = 16;                            // the task word
+constexpr size_t kBatchLdsExtra = 16;                            // the word that names the block's next problem
 
 }  // namespace mcgp

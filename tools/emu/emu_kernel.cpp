@@ -74,7 +74,7 @@ static int run_size(const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offse
                 for (uint32_t t = 0; t < B; ++t)
                     mcgp::reg_simulate<N, true>(&kp, mcgp::smem, t, nullptr, n_sims, sim_offset, (uint32_t)seed,
                                                 (uint32_t)(seed >> 32), orders, fixed_grid, n_chunks, retire_ws.data(), B, 0u,
-                                                mcgp::kTicketChunks, reinterpret_cast<const double *>(mcgp_normal53_table_bits));
+                                                reinterpret_cast<const double *>(mcgp_normal53_table_bits));
                 for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N>(mcgp::smem, t, hist);
                 return 0;
             } else {

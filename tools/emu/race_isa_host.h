@@ -92,6 +92,8 @@ inline uint32_t cvt_u32_f64_sat(double x)
 }
 // the emulated threads run one after another: a wave's turn-th chunk is a fixed one
 inline uint32_t next_ticket(uint32_t *, uint32_t tid, uint32_t turn, int waves) { return turn * (uint32_t)waves + tid / 64u; }
+inline uint32_t peek_ticket(const uint32_t *counter) { return *counter; }
+inline uint32_t first_lane_with(bool pred) { return pred ? 0u : 64u; }
 inline void sched_fence() {}
 inline double ceil_f64(double x) { return std::ceil(x); }
 inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
