@@ -29,6 +29,7 @@
 #pragma once
 #include "race_common.hip.h"
 #include "race_isa.hip.h"
+#include "sort_networks.h"
 
 // Diagnostic builds only (tools/ablate.sh): bit k set = run section k twice (each section is
 // idempotent, results unchanged) so its cost shows up as a time difference.  0 in the product build.
@@ -54,9 +55,6 @@
 // Diagnostic (host build, tests): 1 = _sample_grid takes its exact, dividing path for every draw.
 #ifndef MCGP_GRID_EXACT
 #define MCGP_GRID_EXACT 0
-#endif
-#ifndef MCGP_RESORT_ROUNDS
-#define MCGP_RESORT_ROUNDS 0
 #endif
 #ifndef MCGP_COOPERATIVE_EVENTS
 #define MCGP_COOPERATIVE_EVENTS 1
@@ -172,10 +170,12 @@ struct RegGeo {
     static_assert(oLast < 65536, "row bases must fit the DS immediate offset");
 };
 
-// Knuth, TAOCP 5.2.2 Algorithm M (merge exchange): a sorting network for any N.  Comparators of one (p, q, r, d)
-// step touch disjoint slots; they are grouped two by two (ga / gn) so that two go into one instruction block.
+// The sorting network of the full sort: Knuth, TAOCP 5.2.2 Algorithm M (merge exchange) for any N, or, for the sizes
+// listed in sort_networks.h, two size-optimal half sorters and Batcher's odd-even merge (20 cars: 93 comparators instead
+// of 97; a few of them put their minimum on the HIGHER slot, which cmpx_time does not mind).  Comparators of one step /
+// layer touch disjoint slots; they are grouped two by two (ga / gn) so that two go into one instruction block.
 template <int N>
-struct MergeExchange {
+struct SortNetwork {
     int a[N * 8];
     int b[N * 8];
     int step[N * 8];
@@ -183,20 +183,34 @@ struct MergeExchange {
     int ga[N * 8];          // group -> index of its first comparator
     int gn[N * 8];          // group -> 1 or 2 comparators
     int n_groups;
-    constexpr MergeExchange() : a{}, b{}, step{}, n(0), ga{}, gn{}, n_groups(0)
+    constexpr SortNetwork() : a{}, b{}, step{}, n(0), ga{}, gn{}, n_groups(0)
     {
-        int t = 0, s = 0;
-        while ((1 << t) < N) ++t;
-        for (int p = t > 0 ? 1 << (t - 1) : 0; p > 0; p >>= 1) {
-            int q = 1 << (t - 1), r = 0, d = p;
-            while (true) {
-                for (int i = 0; i < N - d; ++i)
-                    if ((i & p) == r) { a[n] = i; b[n] = i + d; step[n] = s; ++n; }
-                ++s;
-                if (q == p) break;
-                d = q - p;
-                q >>= 1;
-                r = p;
+        const SortNetworkTable *table = nullptr;
+        for (const SortNetworkTable &t : kSortNetworks)
+            if (t.n == N) table = &t;
+        if (table) {
+            // two size-optimal half sorters + Batcher's odd-even merge (sort_networks.h, tools/gen_sort_networks.py)
+            for (int i = 0; i < table->size; ++i) {
+                a[n] = table->pairs[i][0];
+                b[n] = table->pairs[i][1];
+                step[n] = table->pairs[i][2];
+                ++n;
+            }
+        } else {
+            // merge exchange (Knuth, TAOCP 5.3.4, Algorithm M)
+            int t = 0, s = 0;
+            while ((1 << t) < N) ++t;
+            for (int p = t > 0 ? 1 << (t - 1) : 0; p > 0; p >>= 1) {
+                int q = 1 << (t - 1), r = 0, d = p;
+                while (true) {
+                    for (int i = 0; i < N - d; ++i)
+                        if ((i & p) == r) { a[n] = i; b[n] = i + d; step[n] = s; ++n; }
+                    ++s;
+                    if (q == p) break;
+                    d = q - p;
+                    q >>= 1;
+                    r = p;
+                }
             }
         }
         for (int i = 0; i < n;) {
@@ -225,7 +239,7 @@ __device__ __forceinline__ bool cmpx(double &ca, uint32_t &pa, double &cb, uint3
 template <int N, int G>
 __device__ __forceinline__ void network_group(double (&cum)[N], uint32_t (&pk)[N])
 {
-    constexpr MergeExchange<N> net{};
+    constexpr SortNetwork<N> net{};
     constexpr int i = net.ga[G];
     if constexpr (net.gn[G] == 2)
         cmpx_time2(cum[net.a[i]], pk[net.a[i]], cum[net.b[i]], pk[net.b[i]],
@@ -244,7 +258,7 @@ __device__ __forceinline__ void network_sort_impl(double (&cum)[N], uint32_t (&p
 template <int N, size_t... C>
 __device__ __forceinline__ void network_sort_keys_impl(uint32_t (&key)[N], std::index_sequence<C...>)
 {
-    constexpr MergeExchange<N> net{};
+    constexpr SortNetwork<N> net{};
     auto cx = [&](int a, int b) {
         const uint32_t lo = key[a] < key[b] ? key[a] : key[b], hi = key[a] < key[b] ? key[b] : key[a];
         key[a] = lo;
@@ -255,7 +269,7 @@ __device__ __forceinline__ void network_sort_keys_impl(uint32_t (&key)[N], std::
 template <int N>
 __device__ __forceinline__ void network_sort_keys(uint32_t (&key)[N])
 {
-    constexpr MergeExchange<N> net{};
+    constexpr SortNetwork<N> net{};
     network_sort_keys_impl<N>(key, std::make_index_sequence<(size_t)net.n>{});
 }
 
@@ -358,7 +372,7 @@ __device__ __forceinline__ bool ties_in_order(const double (&cum)[N], const uint
 template <int N>
 __device__ __forceinline__ bool network_sort(double (&cum)[N], uint32_t (&pk)[N])
 {
-    constexpr MergeExchange<N> net{};
+    constexpr SortNetwork<N> net{};
     network_sort_impl<N>(cum, pk, std::make_index_sequence<(size_t)net.n_groups>{});
     const bool strict = strictly_increasing<N>(cum);
     MCGP_STAT(13, !strict);
@@ -377,20 +391,8 @@ __device__ __forceinline__ bool network_sort(double (&cum)[N], uint32_t (&pk)[N]
 template <int N>
 __device__ __forceinline__ bool resort_after_overtakes(double (&cum)[N], uint32_t (&pk)[N])
 {
-#if MCGP_RESORT_ROUNDS
-    // experiment: odd-even transposition rounds (independent comparators within a round) instead of the two bubble passes
-#pragma unroll
-    for (int r = 0; r < MCGP_RESORT_ROUNDS; ++r) {
-#pragma unroll
-        for (int i = (r & 1); i + 1 < N; i += 4) {
-            if (i + 3 < N) cmpx_time2(cum[i], pk[i], cum[i + 1], pk[i + 1], cum[i + 2], pk[i + 2], cum[i + 3], pk[i + 3]);
-            else cmpx_time(cum[i], pk[i], cum[i + 1], pk[i + 1]);
-        }
-    }
-#else
     bubble_forward<N, 0>(cum, pk);                 // (0,1), (1,2), .. (N-2,N-1)
     bubble_backward<N, N - 2>(cum, pk);            // (N-3,N-2), .. (0,1): the last slot already holds the maximum
-#endif
     const bool strict = strictly_increasing<N>(cum);
     MCGP_STAT(14, !strict);
     if (__builtin_expect(!strict, 0)) {

@@ -17,8 +17,7 @@ _libs = {}
 # named diagnostic variants of the host build: extra -D flags of csrc/race_kernel_reg.hip.h
 VARIANTS = {
     None: [],
-    'grid_exact': ['-DMCGP_GRID_EXACT=1'],
-    'rr4': ['-DMCGP_RESORT_ROUNDS=4'], 'rr6': ['-DMCGP_RESORT_ROUNDS=6'], 'rr3': ['-DMCGP_RESORT_ROUNDS=3'],      # _sample_grid takes the exact (dividing) path for every draw
+    'grid_exact': ['-DMCGP_GRID_EXACT=1'],      # _sample_grid takes the exact (dividing) path for every draw
 }
 
 
@@ -26,7 +25,7 @@ def build(variant=None):
     LIB = os.path.join(EMU_DIR, 'libmcgp_emu.so' if variant is None else f'libmcgp_emu_{variant}.so')
     tag = '' if variant is None else '_' + variant
     srcs = [os.path.join(EMU_DIR, f) for f in ('emu_kernel.cpp', 'race_isa_host.h', 'hip/hip_runtime.h')]
-    srcs += [os.path.join(CSRC, f) for f in ('race_kernel_reg.hip.h', 'race_common.hip.h', 'params_build.h', 'normal_table.h')]
+    srcs += [os.path.join(CSRC, f) for f in ('race_kernel_reg.hip.h', 'race_common.hip.h', 'params_build.h', 'normal_table.h', 'sort_networks.h')]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         # four translation units (field sizes n % 4 == k) compiled side by side, then linked
         flags = ['-O1', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-I' + EMU_DIR, '-DEMU_PARTS=4']

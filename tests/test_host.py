@@ -195,3 +195,36 @@ def test_device_argument_of_the_drop_in_class():
     if N.lib().mcgp_device_count() == 0:
         with pytest.raises(N.McgpError):
             RaceSimulator(cfg, device='all')                # no CPU path, no silent empty device list
+
+
+def test_generated_sort_networks_sort_every_zero_one_input():
+    """csrc/sort_networks.h (tools/gen_sort_networks.py): every comparator list, parsed from the header, sorts all 2^n
+    zero-one inputs (zero-one principle: it sorts everything), is smaller than merge exchange for its size, is written in
+    layers of disjoint comparators, and equals what the generator builds today."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('gen_sort_networks', os.path.join(root, 'tools', 'gen_sort_networks.py'))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    text = open(os.path.join(root, 'monte_carlo_gp_amd', 'csrc', 'sort_networks.h')).read()
+    found = {}
+    for m in re.finditer(r'kSortNetwork(\d+)\[(\d+)\]\[3\] = \{(.*?)\};', text, re.S):
+        triples = [tuple(int(x) for x in t) for t in re.findall(r'\{(\d+), (\d+), (\d+)\}', m.group(3))]
+        assert len(triples) == int(m.group(2))
+        found[int(m.group(1))] = triples
+    assert sorted(found) == sorted(G.SIZES) and 20 in found and len(found[20]) == 93
+    for n, triples in found.items():
+        net = [(a, b) for a, b, _ in triples]
+        assert all(0 <= a < n and 0 <= b < n and a != b for a, b in net)
+        assert len(net) < G.merge_exchange_size(n)
+        layers = [s for _, _, s in triples]
+        assert layers == sorted(layers)
+        for s in set(layers):
+            wires = [w for a, b, t in triples if t == s for w in (a, b)]
+            assert len(wires) == len(set(wires)), (n, s)
+        assert G.sorts_all_zero_one_inputs(n, net), n
+        built, built_layers = G.build(n)
+        assert built == net and built_layers == layers
+    # the checker itself: a network with one comparator missing is caught
+    assert not G.sorts_all_zero_one_inputs(10, [(a, b) for a, b, _ in found[10]][:-1])
