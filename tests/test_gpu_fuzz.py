@@ -86,3 +86,34 @@ def test_fuzzed_configurations_in_one_batch_launch(require_gpu):
     for i, (k, (_, hist)) in enumerate(zip(names, out)):
         ref = O.Problem(cases[k]).run(n_sims, rng=O.RNG_PHILOX, seed=cases[k]['seed'], sim_offset=7 * i)['hist']
         assert np.array_equal(hist, ref), k
+
+
+def test_batch_with_more_problems_than_blocks(require_gpu):
+    """mcgp_run_batch with 700 ten-car problems of 130 simulations (3 wave-chunks, the last one ragged): more problems than the
+    launch has blocks, so every block walks through several of them (table reloads, the 64-at-a-time scan of the per-problem
+    ticket counters going round the end of the list), and most of a block's waves find a problem's counter already exhausted.
+    Every histogram is the oracle's; seeds, offsets and retirement rates differ from problem to problem."""
+    import copy
+    from monte_carlo_gp_amd import RaceConfig, run_monte_carlo_batch, _native as N
+    base = O.load_case('N10')
+    set_pop = O.load_cases()['set_pop']
+    n_sims, k = 130, 700
+    drivers = list(base['base_pace'])
+    cases = []
+    for i in range(k):
+        c = copy.deepcopy(base)
+        c['config']['total_laps'] = 12 + i % 9
+        c['driver_dnf_rates'] = {d: 0.002 * (1 + (i + j) % 7) for j, d in enumerate(drivers)}
+        c['base_pace'] = {d: v + 0.01 * ((i * 7 + j) % 13) for j, (d, v) in enumerate(base['base_pace'].items())}
+        cases.append(c)
+    problems = [dict(config=RaceConfig(**c['config']), grid_probs=c['grid_probs'], base_pace=c['base_pace'], tire_deg=c['tire_deg'],
+                     driver_variance=c['driver_variance'], driver_dnf_rates=c['driver_dnf_rates'], seed=1000 + i,
+                     track_condition=c['track_condition'], sim_offset=64 * i + 5) for i, c in enumerate(cases)]
+    out = run_monte_carlo_batch(problems, n_sims, set_pop=set_pop)
+    assert N.lib().mcgp_last_kernel_name(0).decode() == 'mcgp::race_kernel_reg_batch<10>'
+    assert len(out) == k
+    for i, (c, (_, hist)) in enumerate(zip(cases, out)):
+        assert (hist.sum(axis=0) == n_sims).all() and (hist.sum(axis=1) == n_sims).all(), i
+        if i % 7 == 0 or i >= k - 3:
+            ref = O.Problem(c).run(n_sims, rng=O.RNG_PHILOX, seed=1000 + i, sim_offset=64 * i + 5)['hist']
+            assert np.array_equal(hist, ref), i
