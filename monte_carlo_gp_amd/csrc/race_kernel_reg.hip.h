@@ -9,7 +9,7 @@
 //
 // Every loop over cars is fully unrolled, so all register indices are compile-time
 // constants; "the car ahead" is simply rank r-1.  Ordering work is a fixed compare-exchange
-// network (Knuth's merge exchange, 97 comparators for N = 20) on (cum, pk) after the lap
+// network (93 comparators for N = 20: SortNetwork below) on (cum, pk) after the lap
 // times have been added, and one forward + one backward bubble pass after an overtake pass
 // (which only moves a few cars by 0.1-0.3 s).  Ties compare pk as an integer: the grid slot sits
 // in its top bits, which is Python's stable-sort order for the reference's grid-ordered lists.
@@ -24,8 +24,8 @@
 // per-(compound, driver) {degradation x factor, pit threshold}, per-compound pace delta, the pit rule, the
 // n x n histogram (u32) and the transposed grid matrix.
 //
-// Random draws of a lap are addressed by the car's PLACE in the field order (its register index): the block of
-// places 2j and 2j+1 is computed right where the two cars' laps are, and never touches LDS.
+// Random draws of a lap are addressed by the car's PLACE in the field order (its register index): the Philox block of
+// places 4j .. 4j+3 is computed right where the four cars' laps are, and never touches LDS.
 #pragma once
 #include "race_common.hip.h"
 #include "race_isa.hip.h"
@@ -554,7 +554,7 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         // degradation per lap of tyre age: compound rate x driver factor, reference :319-322; stored x 2^-16 (exact) so
         // that it multiplies the age field of pk as it stands, (age << 16): one mask instead of a bit-field extract
         *reinterpret_cast<double *>(r) = (P->comp_deg[c] * P->factor[d]) * kAgeFieldUnit;
-        // pit word: threshold << 16, to be compared with (tyre age + 1) << 16 taken straight from pk (:454-465)
+        // pit word: threshold << 16, to be compared with tyre age << 16 taken straight from pk (:454-465: age + 1 > threshold)
         *reinterpret_cast<uint32_t *>(r + 8) = (uint32_t)P->opt_laps[d * kCompStride + c] << 16;
         *reinterpret_cast<uint32_t *>(r + 12) = 0u;
     }
@@ -1312,7 +1312,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const double lap_time = max_abs_f64(ahead_if_dirty, clean + pen_if_dirty);          // :213, :215 (neither is NaN)
                         // pit stop (:450-492): (tyre age + 1) << 16 against the pit word; compound and used-set from
                         // the rule table (pit_rule_word)
-                        const bool pit = run && pit_window && (agef + (1u << k3AgeShift)) > s.pitw;
+                        const bool pit = run && pit_window && agef >= s.pitw;       // age + 1 > threshold (both fields << 16)
                         const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | s.fit;
                         uint32_t p_run = pit ? p_pit : p + (1u << k3AgeShift);
                         uint32_t p_ret = (p & ~k3AgeMask) | retire_bits;
