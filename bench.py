@@ -351,6 +351,12 @@ def main():
                                  'frac_of_mix_ceiling': rate / mix['peak_T_wave_instructions_per_s_for_this_mix'],
                                  'share_four_cycle_class': mix['share_four_cycle'],
                                  'mean_cycles_per_instruction_for_mix': mix['mean_cycles_per_instruction_for_this_mix']})
+                    occ = mix.get('at_three_waves_per_simd')
+                    if occ and abs(float(roof.get('waves_per_simd') or 0) - 3.0) < 0.2:
+                        # the same mix priced at the kernel's own occupancy: at 3 waves per SIMD VOP2 instructions, compares,
+                        # 64-bit conversions and v_mad_u64_u32 measure 25-35 % dearer than at 2 or 4 (r3_valu_peak.json)
+                        roof.update({'peak_for_instruction_mix_at_occupancy': occ['peak_T_wave_instructions_per_s'],
+                                     'frac_of_mix_ceiling_at_occupancy': rate / occ['peak_T_wave_instructions_per_s']})
             except (OSError, ValueError, KeyError):
                 pass
         roof.update({
@@ -359,7 +365,8 @@ def main():
                          'peak_at_fp64_rate = / 4 cycles, the rate behind the 78.6 TFLOP/s vector FP64 peak (the kernel\'s '
                          'instructions are binary64 / VOP3 ones for the most part); peak_for_instruction_mix weights the '
                          'two measured issue costs (tools/valu_peak.hip) by the lap loop\'s instruction classes and is the '
-                         'ceiling to read frac_of_mix_ceiling against; valu_busy_profiled is the rocprof VALUBusy formula, '
+                         'ceiling to read frac_of_mix_ceiling against (costs at 2 / 4 / 8 waves per SIMD; ..._at_occupancy prices the same mix with '
+                         'the costs measured at 3 waves per SIMD, this kernel\'s occupancy at 20 cars); valu_busy_profiled is the rocprof VALUBusy formula, '
                          'which overshoots 1 when 2-cycle instructions are in the mix',
             'hbm_nominal': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': achieved / HBM_PEAK_GBS,

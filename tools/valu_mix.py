@@ -41,7 +41,7 @@ def main():
     text = open(path).read()
     funcs = re.split(r'\n(?=_ZN4mcgp\w+:)', text)
     body = next(f for f in funcs if f.startswith('_ZN4mcgp15race_kernel_regILi20'))
-    cur, cold, classes, ops = None, False, collections.Counter(), collections.Counter()
+    cur, cold, classes, ops, fine = None, False, collections.Counter(), collections.Counter(), collections.Counter()
     for line in body.split('\n'):
         s = line.strip()
         m = re.match(r'\.loc\s+(\d+)\s+(\d+)', s)
@@ -58,6 +58,8 @@ def main():
                  re.match(r'v_(bfe|lshl_add|lshl_or|and_or|or3|xor3|add3|mad_|bfi|alignbit|perm|med3|min3|max3|cndmask_b32_e64|readlane|writelane|mbcnt)', op) is not None)
                 and not op.endswith('_e32'))
         classes['4-cycle class' if four else '2-cycle class'] += 1
+        fine['compare' if op.startswith('v_cmp') else 'convert64' if re.match(r'v_cvt_(f64_|u32_f64|i32_f64)', op) else
+             'mad_u64' if op.startswith('v_mad_u64') else 'other 4-cycle' if four else '2-cycle'] += 1
         ops[op] += 1
     n4, n2 = classes['4-cycle class'], classes['2-cycle class']
     peak = json.load(open(os.path.join(ROOT, 'profiles', 'r3_valu_peak.json')))['waves_per_simd']['4']
@@ -69,6 +71,17 @@ def main():
                mean_cycles_per_instruction_for_this_mix=mean,
                peak_T_wave_instructions_per_s_for_this_mix=1024 * 2.4e9 / mean / 1e12,
                top_opcodes=ops.most_common(14))
+    # The same mix at the kernel's OWN occupancy (N = 20: one block of 768 threads, 3 waves per SIMD), where the measured costs
+    # are higher for several classes: a VOP2 instruction 2.85 cycles instead of 2.25, a compare 5.4, a 64-bit conversion 5.1,
+    # v_mad_u64_u32 5.65 (profiles/r3_valu_peak.json, column "3 (one block of 768)").
+    p3 = json.load(open(os.path.join(ROOT, 'profiles', 'r3_valu_peak.json')))['waves_per_simd']['3 (one block of 768)']
+    cost3 = {'compare': (p3['v_cmp_gt_f64 (vcc)'] + p3['v_cmp_lt_u32 (vcc)']) / 2, 'convert64': p3['v_cvt_f64_u32'],
+             'mad_u64': p3['v_mad_u64_u32'],
+             'other 4-cycle': sum(p3[k] for k in ('v_add_f64', 'v_mul_f64', 'v_min_f64', 'v_bfe_u32', 'v_and_or_b32', 'v_cndmask_b32_e64 (SGPR mask)')) / 6,
+             '2-cycle': sum(p3[k] for k in ('v_and_b32', 'v_xor_b32', 'v_add_u32')) / 3}
+    mean3 = sum(fine[k] * cost3[k] for k in fine) / sum(fine.values())
+    out['at_three_waves_per_simd'] = dict(classes=dict(fine), cycles=cost3, mean_cycles_per_instruction=mean3,
+                                          peak_T_wave_instructions_per_s=1024 * 2.4e9 / mean3 / 1e12)
     sys.path.insert(0, ROOT)
     from monte_carlo_gp_amd import _native as N
     out['source_hash'] = N.source_hash()
