@@ -326,7 +326,7 @@ def main():
                          'active_lane_ratio': pc.get('active_lane_ratio'), 'waves_per_simd': pc.get('waves_per_simd'),
                          'scratch_bytes_per_lane': int(pc.get('kernel', {}).get('Scratch_Size', 0) or 0),
                          'source_hash': pc.get('source_hash'),
-                         'counters': f'profiles/{COUNTERS_FILE} (rocprofv3 --pmc, tools/profile_r4.sh), stamped with the '
+                         'counters': f'profiles/{COUNTERS_FILE} (rocprofv3 --pmc, tools/profile.sh), stamped with the '
                                      'source hash the loaded binary reports (mcgp_build_hash)'})
             # Lane-level view of the same counters.  A wave-instruction issues for 64 lanes whether they
             # are masked or not; weighting by the measured share of active lanes gives the USEFUL lane-operations and
