@@ -53,7 +53,7 @@ def test_generic_and_register_kernels_agree(require_gpu, monkeypatch):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 7, 19, 24, 25, 32])
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 9, 17, 18, 19, 22, 24, 25, 26, 32])
 def test_other_field_sizes(require_gpu, n):
     """Field sizes beyond the golden cases (generic LDS kernel and further register instantiations),
     up to the ABI maximum, with an all-zero grid column (Q18 uniform fallback)."""

@@ -88,7 +88,7 @@ def test_inverse_normal_transform_matches_the_oracle_word_for_word():
         assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), hex(w)
 
 
-@pytest.mark.parametrize('n', [1, 2, 5, 13, 25, 28, 32])
+@pytest.mark.parametrize('n', [1, 2, 5, 9, 13, 17, 18, 22, 25, 26, 28, 32])
 def test_field_sizes_up_to_the_abi_maximum(n):
     """Every register instantiation is the same source; sizes beyond the golden / fuzz cases, with an all-zero
     grid column (uniform fallback, reference :126-129) and per-driver spreads."""
