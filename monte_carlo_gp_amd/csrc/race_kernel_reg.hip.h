@@ -156,6 +156,7 @@ struct RegGeo {
     static constexpr uint32_t oIc = oDrvB + (kMaxCars + N) * 16;  // [compound][driver] {eff f64, pit word u32, DNF threshold u32}
     static constexpr uint32_t oComp = oIc + ((kNumCompounds - 1) * kMaxCars + N) * 16;   // {delta f64, pad} x 8, 16 B each
     static constexpr uint32_t oDrs = oComp + kCompStride * 16;    // {0.0, drs_delta}                          (lap time)
+    static constexpr uint32_t oPit = oDrs + 16;                   // {0.0, pit_loss}                           (the stop's time, by flag)
     static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, drs_delta 2^31}                     (overtake pace)
     static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
     static constexpr uint32_t oHist = oLut + 128;                 // u32[N x N]
@@ -461,6 +462,12 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #ifndef MCGP_STEP_BATCH
 #define MCGP_STEP_BATCH 4          // slots whose LDS gathers (and Philox blocks) are in flight together in the lap step
 #endif
+#ifndef MCGP_RETIRE_VGPR
+#define MCGP_RETIRE_VGPR 1
+#endif
+#ifndef MCGP_PIT_TABLE
+#define MCGP_PIT_TABLE 1          // the lap step adds the stop's time from a {0.0, pit_loss} table instead of selecting it
+#endif
 #ifndef MCGP_DISTINCT_PATH
 #define MCGP_DISTINCT_PATH 1       // update_positions_reg<N, true> for the wave-laps whose fields have no equal times
 #endif
@@ -547,6 +554,7 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         // {0.0, drs_delta}: a car's row is at byte offset (pk & k3Drs)
         *reinterpret_cast<double *>(smem + G::oDrs + tid * k3Drs) = tid ? P->drs_delta : 0.0;
         *reinterpret_cast<double *>(smem + G::oDrsB + tid * k3Drs) = tid ? P->drs_delta * 2147483648.0 : 0.0;
+        *reinterpret_cast<double *>(smem + G::oPit + tid * 8u) = tid ? P->pit_loss : 0.0;
     }
     for (uint32_t i = tid; i < (uint32_t)kNumCompounds * N; i += B) {
         const uint32_t c = i / N, d = i % N;
@@ -1231,6 +1239,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const bool pit_window = remaining_laps > 5;                                     // :451
                 const uint32_t lut_base = G::oLut + 32u * (uint32_t)pit_regime(remaining_laps);  // this lap's row of the pit rule
                 const uint32_t retire_bits = k3Dnf | ((uint32_t)lap << k3AgeShift);
+#if MCGP_RETIRE_VGPR
+                // in a vector register, so that (p & ~age) | retire_word is one v_and_or_b32 (an instruction takes one scalar operand)
+                uint32_t retire_word = retire_bits;
+                pin(retire_word);
+#define MCGP_RETIRE_WORD retire_word
+#else
+#define MCGP_RETIRE_WORD retire_bits
+#endif
                 double carry = 0.0;
 #pragma unroll
                 for (int i0 = 0; i0 < ((MCGP_SKIP & 64) ? 0 : N); i0 += MCGP_STEP_BATCH) {
@@ -1315,14 +1331,23 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const bool pit = run && pit_window && agef >= s.pitw;       // age + 1 > threshold (both fields << 16)
                         const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | s.fit;
                         uint32_t p_run = pit ? p_pit : p + (1u << k3AgeShift);
-                        uint32_t p_ret = (p & ~k3AgeMask) | retire_bits;
+                        uint32_t p_ret = (p & ~k3AgeMask) | MCGP_RETIRE_WORD;
                         pin(p_run);              // both computed for every lane: the merge below stays a pair of selects
                         pin(p_ret);
                         const uint32_t p_act = dnf_hit ? p_ret : p_run;
                         pk[i] = active ? p_act : p;
+#if MCGP_PIT_TABLE
+                        // :218, :464 as two additions for every car: the lap time or +0.0 (not running), then the stop's time or
+                        // +0.0 from a two-entry LDS table (an offset select and a read instead of two 64-bit-encoded selects).
+                        // x + 0.0 is x for every x but -0.0, which no cumulative time is.
+                        const double lap_add = run ? lap_time : 0.0;
+                        const double pit_add = lds_ld<double>(G::oPit + (pit ? 8u : 0u));           // (pit implies run)
+                        cum[i] = (cum[i] + lap_add) + pit_add;
+#else
                         const double t_run = cum[i] + lap_time;                                     // :218
                         const double t_pit = t_run + pit_loss;                                      // :464
                         cum[i] = pit ? t_pit : run ? t_run : cum[i];                                // (pit implies run)
+#endif
                         pin(cum[i]);             // done HERE: not sunk, with its masks and lap time, to where it is used
                         lds_st<double>(G::oLast + s.la, lap_time);                                  // :219
                     }
