@@ -462,12 +462,6 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #ifndef MCGP_STEP_BATCH
 #define MCGP_STEP_BATCH 4          // slots whose LDS gathers (and Philox blocks) are in flight together in the lap step
 #endif
-#ifndef MCGP_RETIRE_VGPR
-#define MCGP_RETIRE_VGPR 1
-#endif
-#ifndef MCGP_PIT_TABLE
-#define MCGP_PIT_TABLE 1          // the lap step adds the stop's time from a {0.0, pit_loss} table instead of selecting it
-#endif
 #ifndef MCGP_DISTINCT_PATH
 #define MCGP_DISTINCT_PATH 1       // update_positions_reg<N, true> for the wave-laps whose fields have no equal times
 #endif
@@ -1019,7 +1013,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             // eight 64-bit values that would otherwise push as many lane masks and addresses out to scratch.
             const KParams *Pl = P;
             pin_ptr(Pl);
-            const double pit_loss = Pl->pit_loss, od31 = Pl->overtake_delta_31, dirty_thr = Pl->dirty_thr;
+            const double od31 = Pl->overtake_delta_31, dirty_thr = Pl->dirty_thr;
             const double dirty_pen_lap = lap == 2 ? 0.0 : Pl->dirty_pen;         // (no dirty-air constraint in lap 2: see the lap step)
             const uint64_t t_red = WIDE ? Pl->t53_red : Pl->t_red, t_sc = WIDE ? Pl->t53_sc : Pl->t_sc,
                            t_vsc = WIDE ? Pl->t53_vsc : Pl->t_vsc, t_vsc_tire = WIDE ? Pl->t53_vsc_tire : Pl->t_vsc_tire;
@@ -1238,15 +1232,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const double fuel_effect = (110.0 - fuel) * 0.03;
                 const bool pit_window = remaining_laps > 5;                                     // :451
                 const uint32_t lut_base = G::oLut + 32u * (uint32_t)pit_regime(remaining_laps);  // this lap's row of the pit rule
-                const uint32_t retire_bits = k3Dnf | ((uint32_t)lap << k3AgeShift);
-#if MCGP_RETIRE_VGPR
                 // in a vector register, so that (p & ~age) | retire_word is one v_and_or_b32 (an instruction takes one scalar operand)
-                uint32_t retire_word = retire_bits;
+                uint32_t retire_word = k3Dnf | ((uint32_t)lap << k3AgeShift);
                 pin(retire_word);
-#define MCGP_RETIRE_WORD retire_word
-#else
-#define MCGP_RETIRE_WORD retire_bits
-#endif
                 double carry = 0.0;
 #pragma unroll
                 for (int i0 = 0; i0 < ((MCGP_SKIP & 64) ? 0 : N); i0 += MCGP_STEP_BATCH) {
@@ -1331,23 +1319,17 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         const bool pit = run && pit_window && agef >= s.pitw;       // age + 1 > threshold (both fields << 16)
                         const uint32_t p_pit = (p & ~(k3CompMask | k3UsedMask | k3AgeMask)) | s.fit;
                         uint32_t p_run = pit ? p_pit : p + (1u << k3AgeShift);
-                        uint32_t p_ret = (p & ~k3AgeMask) | MCGP_RETIRE_WORD;
+                        uint32_t p_ret = (p & ~k3AgeMask) | retire_word;
                         pin(p_run);              // both computed for every lane: the merge below stays a pair of selects
                         pin(p_ret);
                         const uint32_t p_act = dnf_hit ? p_ret : p_run;
                         pk[i] = active ? p_act : p;
-#if MCGP_PIT_TABLE
                         // :218, :464 as two additions for every car: the lap time or +0.0 (not running), then the stop's time or
                         // +0.0 from a two-entry LDS table (an offset select and a read instead of two 64-bit-encoded selects).
                         // x + 0.0 is x for every x but -0.0, which no cumulative time is.
                         const double lap_add = run ? lap_time : 0.0;
                         const double pit_add = lds_ld<double>(G::oPit + (pit ? 8u : 0u));           // (pit implies run)
                         cum[i] = (cum[i] + lap_add) + pit_add;
-#else
-                        const double t_run = cum[i] + lap_time;                                     // :218
-                        const double t_pit = t_run + pit_loss;                                      // :464
-                        cum[i] = pit ? t_pit : run ? t_run : cum[i];                                // (pit implies run)
-#endif
                         pin(cum[i]);             // done HERE: not sunk, with its masks and lap time, to where it is used
                         lds_st<double>(G::oLast + s.la, lap_time);                                  // :219
                     }
