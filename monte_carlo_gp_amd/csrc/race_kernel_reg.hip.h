@@ -1234,7 +1234,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 const uint32_t lut_base = G::oLut + 32u * (uint32_t)pit_regime(remaining_laps);  // this lap's row of the pit rule
                 // in a vector register, so that (p & ~age) | retire_word is one v_and_or_b32 (an instruction takes one scalar operand)
                 uint32_t retire_word = k3Dnf | ((uint32_t)lap << k3AgeShift);
-                pin(retire_word);
+                if constexpr (reg_min_waves(N) <= 3) pin(retire_word);      // (at 4+ waves per SIMD the register it takes is spilled)
                 double carry = 0.0;
 #pragma unroll
                 for (int i0 = 0; i0 < ((MCGP_SKIP & 64) ? 0 : N); i0 += MCGP_STEP_BATCH) {
