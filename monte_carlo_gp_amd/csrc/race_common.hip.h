@@ -122,18 +122,18 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-// One 32-bit word -> N(0,1): piecewise-cubic inverse CDF (tools/gen_normal_table.py).  `row(k)` returns the
-// k-th coefficient row as a float4.
+// One 32-bit word -> N(0,1): piecewise-cubic inverse CDF (tools/gen_normal_table.py).  The row of a deviate is named by
+// its byte offset `off` from a base kNormalRowBias rows BEFORE the table (the offset is a bit field of a float, whose
+// biased exponent starts at 131: rows 48 .. 495 of that base); `row_of(off)` returns the row as a float4.
 // (in two steps, so that a caller with several deviates to make can fetch all their rows before evaluating any)
-__device__ __forceinline__ void normal_prepare(uint32_t w, uint32_t &row, float &t)
+constexpr uint32_t kNormalRowBias = 48;
+__device__ __forceinline__ void normal_prepare(uint32_t w, uint32_t &off, float &t)
 {
-    // m + 16 has its leading one in bit 4 .. 31: c = clz picks the octave, the next four bits the cell, the rest is the
-    // offset inside the cell -- no special case for the smallest m, no select (tools/gen_normal_table.py)
-    const uint32_t mm = (w & 0x7fffffffu) + 16u;
-    const uint32_t c = (uint32_t)__clz((int)mm);
-    const uint32_t x = mm << c;
-    row = 16u * c + ((x >> 27) & 15u);
-    t = (float)(((x & 0x07ffffffu) << 1) | (1u << c));                      // cell coordinate x 2^28
+    // float(m + 16): exponent 4 .. 31 = the octave, its four leading mantissa bits = the cell, the other 19 = the offset
+    // inside the cell -- the conversion does the count-leading-zeros and the shifts (tools/gen_normal_table.py)
+    const uint32_t b = __float_as_uint((float)((w & 0x7fffffffu) + 16u));
+    off = (b >> 15) & 0x1ff0u;
+    t = (float)(b & 0x7ffffu);                                               // cell coordinate x 2^19
 }
 __device__ __forceinline__ float normal_evaluate(uint32_t w, const float4 cf, float t)
 {
@@ -146,10 +146,10 @@ __device__ __forceinline__ float normal_evaluate(uint32_t w, const float4 cf, fl
 template <typename RowFn>
 __device__ __forceinline__ float normal_from_u32_rows(uint32_t w, RowFn row_of)
 {
-    uint32_t row;
+    uint32_t off;
     float t;
-    normal_prepare(w, row, t);
-    return normal_evaluate(w, row_of(row), t);
+    normal_prepare(w, off, t);
+    return normal_evaluate(w, row_of(off), t);
 }
 
 // Reference-width normal: z0 = Phi^-1((q + 0.5) / 2^53) < 0 for the 52-bit tail index q, degree-7 polynomial on
@@ -187,7 +187,7 @@ constexpr uint32_t kCompanion = 0x8000u;         // counter word 3 of a draw's c
 
 __device__ __forceinline__ float normal_from_u32(uint32_t w, const float4 *__restrict__ tab)
 {
-    return normal_from_u32_rows(w, [tab](uint32_t row) -> float4 { return tab[row]; });
+    return normal_from_u32_rows(w, [tab](uint32_t off) -> float4 { return tab[(off >> 4) - kNormalRowBias]; });
 }
 
 __device__ __forceinline__ double u32_to_unit(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }

@@ -150,8 +150,7 @@ struct RegGeo {
     static constexpr int B = 64 * kWaves;                         // threads per block
     // block-shared tables first: their bases (and the row bases below) fit the 16-bit immediate offset of a DS
     // instruction, so an address is just the bit field taken from pk
-    static constexpr uint32_t oNorm = 0;                          // float4[kNormalRows]
-    static constexpr uint32_t oDrvA = oNorm + kNormalRows * 16;   // {var, base} x N drivers, 16 B each   (lap step)
+    static constexpr uint32_t oDrvA = 0;                          // {var, base} x N drivers, 16 B each   (lap step)
     static constexpr uint32_t oDrvB = oDrvA + N * 16;             // {base, deg} 2^31 x N drivers; at +32 entries {NaN, NaN} x N  (overtake pace)
     static constexpr uint32_t oIc = oDrvB + (kMaxCars + N) * 16;  // [compound][driver] {eff f64, pit word u32, DNF threshold u32}
     static constexpr uint32_t oComp = oIc + ((kNumCompounds - 1) * kMaxCars + N) * 16;   // {delta f64, pad} x 8, 16 B each
@@ -159,7 +158,9 @@ struct RegGeo {
     static constexpr uint32_t oPit = oDrs + 16;                   // {0.0, pit_loss}                           (the stop's time, by flag)
     static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, drs_delta 2^31}                     (overtake pace)
     static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
-    static constexpr uint32_t oHist = oLut + 128;                 // u32[N x N]
+    static constexpr uint32_t oNorm = oLut + 128;                 // float4[kNormalRows]; addressed from kNormalRowBias rows before it
+    static constexpr uint32_t oHist = oNorm + kNormalRows * 16;   // u32[N x N]
+    static_assert(oNorm >= kNormalRowBias * 16, "the inverse-normal rows are addressed through a base 48 rows before the table");
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
     static constexpr uint32_t oW = oGrid + (uint32_t)align16((size_t)N * N * 8);   // [kWordRows][B] u32, 16-byte aligned (odd N: padded)
     static constexpr uint32_t oLast = oW + (uint32_t)kWordRows * B * 4;      // [N][B] f64
@@ -622,7 +623,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     auto last_of = [&](uint32_t p) -> uint32_t { return ((p >> k3IdShift) & 31u) * (uint32_t)(B * 8) + tid8; };
     // ... and the byte of grid slot `pos` in the W plane (the sampled grid, before lap 1)
     auto grid_byte = [&](int pos) -> uint32_t { return G::oW + (uint32_t)(pos >> 2) * (B * 4) + tid4 + (uint32_t)(pos & 3); };
-    auto norm_row = [&](uint32_t row) -> float4 { return lds_ld_float4(G::oNorm + row * 16u); };
+    auto norm_row = [&](uint32_t off) -> float4 { return lds_ld_float4(G::oNorm - kNormalRowBias * 16u + off); };
 
     const double dirty_thr = P->dirty_thr;                     // (lap 1; the lap loop reads its constants per lap)
     const float kNaN = __uint_as_float(0x7fc00000u);

@@ -209,13 +209,14 @@ static inline float bits_to_float(uint32_t b)
  * kernel evaluates the same expression and gets the same bits. */
 float orc_normal_from_u32(uint32_t w)
 {
-    /* m + 16 has its leading one in bit 4 .. 31: c = clz picks the octave, the next four bits the cell, the rest is
-     * the offset inside the cell (tools/gen_normal_table.py: no special case for the smallest m) */
-    const uint32_t mm = (w & 0x7fffffffu) + 16u;
-    const int c = __builtin_clz(mm);
-    const uint32_t x = mm << c;
-    const uint32_t row = 16u * (uint32_t)c + ((x >> 27) & 15u);
-    const float t = (float)(((x & 0x07ffffffu) << 1) | (1u << c));          /* cell coordinate x 2^28 */
+    /* float(m + 16): exponent 4 .. 31 = the octave, its four leading mantissa bits = the cell, the other 19 = the offset
+     * inside the cell (tools/gen_normal_table.py: no special case for the smallest m); the rows are stored from
+     * exponent 4 on, i.e. from row (131 mod 32) * 16 = 48 of the bit field */
+    const float fm = (float)((w & 0x7fffffffu) + 16u);                      /* round to nearest even */
+    uint32_t b;
+    memcpy(&b, &fm, 4);
+    const uint32_t row = ((b >> 19) & 0x1ffu) - 48u;
+    const float t = (float)(b & 0x7ffffu);                                  /* cell coordinate x 2^19 */
     const unsigned int *cf = &mcgp_normal_table_bits[4 * row];
     float z = __builtin_fmaf(bits_to_float(cf[3]), t, bits_to_float(cf[2]));
     z = __builtin_fmaf(z, t, bits_to_float(cf[1]));

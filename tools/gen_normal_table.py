@@ -7,20 +7,20 @@ CPU oracle and the HIP kernel produce the same bits by construction):
 
     sign = w >> 31,  m = w & 0x7fffffff,  tail probability p = (m + 0.5) / 2^32 in (0, 0.5)
     mm = m + 16                   (16 .. 2^31 + 15: no special case for the smallest m)
-    c  = clz(mm) (0 .. 27),  x = mm << c  (bit 31 set),  k = (x >> 27) & 15,
-    frac = x & 0x07ffffff         (the offset inside the cell, left-aligned: its low c bits are zero)
-    t  = float((frac << 1) | (1 << c))                   = (cell coordinate in (0, 1)) x 2^28
-    row = 16 c + k
-    z0 = fmaf(fmaf(fmaf(c3, t, c2), t, c1), t, c0)      (binary32; the row's coefficients carry the 2^-28 per power)
-    z  = bits(z0) ^ (w & 0x80000000)                     (z0 = Phi^-1(p) < 0; the sign of w flips it)
+    f  = float(mm)                (binary32, round to nearest even -- v_cvt_f32_u32 / a C cast), b = its bit pattern
+    e  = exponent of f (4 .. 31), k = its four leading mantissa bits, the other 19 = the offset inside the cell
+    off = (b >> 15) & 0x1ff0      = 16 bytes x (16 (E mod 32) + k),  E = e + 127 the biased exponent: E mod 32 = 3 .. 30
+    t  = float(b & 0x7ffff)                               = (cell coordinate in [0, 1)) x 2^19
+    z0 = fmaf(fmaf(fmaf(c3, t, c2), t, c1), t, c0)       (binary32; the row's coefficients carry the 2^-19 per power)
+    z  = bits(z0) ^ (w & 0x80000000)                      (z0 = Phi^-1(p) < 0; the sign of w flips it)
 
-Cell (c, k) holds the m with  mm >> (27 - c) == 16 + k,  i.e.  m = ((16 + k) << sh) - 16 + r,  sh = 27 - c,
-r < 2^sh, and the cell coordinate of m is (r + 0.5) / 2^sh.  Every row holds the cubic that interpolates
-Phi^-1((m_lo + coordinate x 2^sh) / 2^32) at the four Chebyshev nodes of the cell, rounded to binary32; the 16 cells
-of width one (c = 27: the 16 smallest m) hold the constant.  448 rows x 4 coefficients = 7168 B.
-
-(Rounds 1-3 special-cased m < 16 with a select and built t from an extracted remainder: four more instructions per
-deviate on the device; the deviates of the two schemes agree to the table's accuracy.)
+The float conversion does what a count-leading-zeros, three shifts, two shift-and-merge operations and a conversion did
+in rounds 1-4 (seven instructions for eleven on the device).  Cell (e, k) holds the f with f in
+[2^e (1 + k/16), 2^e (1 + (k+1)/16)); up to 2^24 every mm is its own f, above that f is mm rounded to 24 bits (a
+relative 2^-24 in the tail probability: 1e-7 in the deviate at most).  Every row holds the cubic that interpolates
+Phi^-1((f - 15.5) / 2^32) at the four Chebyshev nodes of the cell, rounded to binary32; the 16 cells of width one
+(e = 4: the 16 smallest m) hold the constant.  Rows are stored in the order of `off`, 16 (e - 4) + k, and addressed
+through a base that lies 48 rows (kNormalRowBias) before the table: 448 rows x 4 coefficients = 7168 B.
 
 Writes TWO byte-identical copies of the table (bit patterns as uint32):
   oracle/normal_table.h                      (test infrastructure)
@@ -38,22 +38,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NROWS = 28 * 16
 
 
+ROW_BIAS = 48                      # (E mod 32) * 16 of the first exponent, e = 4: E = 131
+
+
 def rows():
     tab = np.zeros((NROWS, 4), np.float64)
     # Chebyshev nodes on [0, 1]
     j = np.arange(4)
     nodes = 0.5 - 0.5 * np.cos((2 * j + 1) * np.pi / 8)
     V = np.vander(nodes, 4, increasing=True)
-    for c in range(28):
-        sh = 27 - c
+    for e in range(4, 32):
+        width = 2.0 ** (e - 4)
         for k in range(16):
-            m_lo = ((16 + k) << sh) - 16
-            if sh == 0:
-                tab[16 * c + k, 0] = ndtri((m_lo + 0.5) / 2.0 ** 32)         # one m per cell: the constant
+            lo = 2.0 ** e * (1 + k / 16.0)
+            r = 16 * (e - 4) + k
+            if e == 4:
+                tab[r, 0] = ndtri((lo - 15.5) / 2.0 ** 32)                    # one m per cell: the constant
                 continue
-            p = (m_lo + nodes * 2.0 ** sh) / 2.0 ** 32
+            p = (lo + nodes * width - 15.5) / 2.0 ** 32
             coef = np.linalg.solve(V, ndtri(p))                               # in the cell coordinate
-            tab[16 * c + k] = coef * 2.0 ** (-28.0 * np.arange(4))            # in t = coordinate x 2^28
+            tab[r] = coef * 2.0 ** (-19.0 * np.arange(4))                     # in t = coordinate x 2^19
     return tab.astype(np.float32)
 
 
@@ -62,16 +66,12 @@ def eval_table(tab, w):
     w = w.astype(np.uint64)
     sign = (w >> np.uint64(31)) & np.uint64(1)
     m = (w & np.uint64(0x7fffffff)).astype(np.int64)
-    mm = m + 16
-    hb = np.floor(np.log2(mm.astype(np.float64))).astype(np.int64)
-    hb = np.where((np.int64(1) << hb) > mm, hb - 1, hb)
-    c = 31 - hb
-    x = (mm << c) & 0xffffffff
-    k = (x >> 27) & 15
-    frac = x & 0x07ffffff
-    t = ((frac << 1) | (np.int64(1) << c)).astype(np.float32)
-    cf = tab[16 * c + k]
-    f = lambda a, b, cc: (a.astype(np.float64) * b.astype(np.float64) + cc.astype(np.float64)).astype(np.float32)
+    mm = (m + 16).astype(np.uint32)
+    b = mm.astype(np.float32).view(np.uint32).astype(np.int64)               # round to nearest even
+    off = (b >> 15) & 0x1ff0
+    t = (b & 0x7ffff).astype(np.float32)
+    cf = tab[(off >> 4) - ROW_BIAS]
+    f = lambda a, b_, cc: (a.astype(np.float64) * b_.astype(np.float64) + cc.astype(np.float64)).astype(np.float32)
     z = f(f(f(cf[:, 3], t, cf[:, 2]), t, cf[:, 1]), t, cf[:, 0])
     return np.where(sign == 1, -z, z), (m + 0.5) / 2.0 ** 32, sign
 
@@ -82,7 +82,9 @@ def main():
     w = np.concatenate([rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint64),
                         np.arange(0, 4096, dtype=np.uint64),
                         (np.uint64(1) << np.arange(0, 32, dtype=np.uint64)),
-                        (np.uint64(1) << np.arange(1, 32, dtype=np.uint64)) - np.uint64(1)])
+                        (np.uint64(1) << np.arange(1, 32, dtype=np.uint64)) - np.uint64(1),
+                        (np.uint64(1) << np.arange(5, 32, dtype=np.uint64)) - np.uint64(17),
+                        np.uint64(0x7fffffff) - np.arange(0, 64, dtype=np.uint64)])
     z, p, sign = eval_table(tab, w)
     exact = np.where(sign == 1, -ndtri(p), ndtri(p))
     err = np.abs(z - exact)
@@ -97,7 +99,7 @@ def main():
         os.makedirs(os.path.dirname(full), exist_ok=True)
         with open(full, 'w') as f:
             f.write(f'/* GENERATED by tools/gen_normal_table.py -- do not edit.  Copy for: {who}.\n'
-                    f' * Piecewise-cubic inverse normal CDF, {NROWS} rows (16 clz + k) x 4 binary32 coefficients (c0..c3),\n'
+                    f' * Piecewise-cubic inverse normal CDF, {NROWS} rows (16 (exponent - 4) + k) x 4 binary32 coefficients (c0..c3),\n'
                     f' * stored as IEEE-754 bit patterns.  See the generator for the row/t mapping. */\n'
                     f'#ifndef {guard}\n#define {guard}\n'
                     f'#define MCGP_NORMAL_ROWS {NROWS}\n'
