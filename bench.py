@@ -197,6 +197,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the S78 and orders-mode side measurements')
     ap.add_argument('--orders', action='store_true', help='the timed steps also write the per-simulation finishing orders')
+    ap.add_argument('--deviates', type=int, default=32, choices=(32, 53),
+                    help='53: the timed steps run at the reference\'s deviate width (race_kernel_reg_wide; tools/profile.sh)')
     args = ap.parse_args()
 
     import torch
@@ -306,7 +308,7 @@ def main():
                     launch={'grid': g.value, 'block': b.value, 'lds_bytes': lds.value})
 
     t_gpu0 = time.perf_counter()
-    r = run_workload(args.workload, args.steps, args.warmup, with_orders=args.orders)
+    r = run_workload(args.workload, args.steps, args.warmup, with_orders=args.orders, deviates=args.deviates)
     if rank == 0:
         n, L, kavg_ms, hist = r['n'], r['L'], r['kernel_ms'], r['hist']
         achieved = per_gpu * ALGORITHMIC_BYTES_PER_SIM / (kavg_ms * 1e-3) / 1e9

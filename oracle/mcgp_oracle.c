@@ -376,11 +376,11 @@ static double draw_dnf(rng_t *r, int lap, int who)
  * drawn here from one word.  PHILOX: 32-bit word against 32-bit thresholds, exactly what the HIP kernels compute
  * (csrc/race_common.hip.h: draw_retirement_lap).  PHILOX53: the same word refined to 53 bits (left-aligned in 64)
  * against 64-bit thresholds S_2 = q, S_{k+1} = floor(S_k q / 2^64), q = 2^64 - ceil(p 2^64). */
-static int philox_retirement_lap(const rng_t *r, int driver, double p, int total_laps)
+/* (the chain on given words: `w` the draw's word, `extra21` the 21 refinement bits of its companion, PHILOX53 only) */
+static int retirement_lap_of_words(uint32_t w, uint32_t extra21, int wide, double p, int total_laps)
 {
-    const uint32_t w = philox_word(r, 0u, PURPOSE_RETIRE, (uint32_t)driver >> 2, driver & 3);
     if (!(p > 0.0)) return 0;                                              /* also NaN: `u < nan` is false */
-    if (r->mode != MCGP_ORACLE_RNG_PHILOX53) {
+    if (!wide) {
         const double x = p * 4294967296.0;                                 /* exact */
         const uint64_t t = x >= 4294967296.0 ? 4294967296ull : (uint64_t)ceil(x);
         const uint32_t q = (uint32_t)(4294967296ull - t);
@@ -391,7 +391,7 @@ static int philox_retirement_lap(const rng_t *r, int driver, double p, int total
         }
         return 0;
     }
-    const uint64_t Q = ((uint64_t)w << 32) | ((uint64_t)philox_extra21(r, 0u, PURPOSE_RETIRE, (uint32_t)driver >> 2, driver & 3) << 11);
+    const uint64_t Q = ((uint64_t)w << 32) | ((uint64_t)extra21 << 11);
     if (p >= 1.0) return total_laps >= 2 ? 2 : 0;
     const double x = p * 18446744073709551616.0;                           /* exact: p 2^64 < 2^64 */
     const uint64_t t = (uint64_t)ceil(x);                                  /* >= 1 */
@@ -402,6 +402,19 @@ static int philox_retirement_lap(const rng_t *r, int driver, double p, int total
         S = (uint64_t)(((unsigned __int128)S * (unsigned __int128)q) >> 64);
     }
     return 0;
+}
+static int philox_retirement_lap(const rng_t *r, int driver, double p, int total_laps)
+{
+    const uint32_t w = philox_word(r, 0u, PURPOSE_RETIRE, (uint32_t)driver >> 2, driver & 3);
+    const int wide = r->mode == MCGP_ORACLE_RNG_PHILOX53;
+    if (!(p > 0.0)) return 0;
+    return retirement_lap_of_words(w, wide ? philox_extra21(r, 0u, PURPOSE_RETIRE, (uint32_t)driver >> 2, driver & 3) : 0u,
+                                   wide, p, total_laps);
+}
+/* test hook (tests/test_philox_layers.py): the retirement law on given words */
+int orc_retirement_lap(uint32_t w, uint32_t extra21, int wide, double p, int total_laps)
+{
+    return retirement_lap_of_words(w, extra21, wide, p, total_laps);
 }
 static double draw_overtake(rng_t *r, int lap, int pass, int attempt)
 {

@@ -96,6 +96,10 @@ float orc_normal_from_u32(uint32_t w);
 double orc_phi_inverse_tail(uint64_t q53, float z_start);
 /* the same value in the form the device computes it: degree-7 table, explicit fma (normal53_table.h) */
 double orc_normal53_tail(uint64_t q53);
+/* test hook: the lap (2 .. total_laps, 0 = none) on which a car with per-lap retirement probability p retires, from the
+ * draw's word (and, wide != 0, the 21 refinement bits of its companion): the once-per-race law of the counter-based
+ * back-ends (reference src/simulation.py:190-197 drawn as one geometric variate) */
+int orc_retirement_lap(uint32_t w, uint32_t extra21, int wide, double p, int total_laps);
 
 /* Run n_sims simulations.
  *   grid_probs  n x n row-major [driver][slot]

@@ -45,6 +45,19 @@ extern "C" float emu_normal_from_u32(uint32_t w)
 {
     return mcgp::normal_from_u32(w, reinterpret_cast<const float4 *>(mcgp_normal_table_bits));
 }
+// ... its binary64 transform of the reference-width build ...
+extern "C" double emu_normal53(uint32_t w, uint32_t companion)
+{
+    return mcgp::normal53(w, companion, reinterpret_cast<const double *>(mcgp_normal53_table_bits));
+}
+// ... and the once-per-race retirement draw with the thresholds the parameter block carries (params_build.h)
+extern "C" uint32_t emu_draw_retirement_lap(uint32_t w, double p, int total_laps)
+{
+    return mcgp::draw_retirement_lap(w, mcgp::threshold(p), total_laps);
+}
+extern "C" unsigned long long emu_threshold(double p) { return mcgp::threshold(p); }
+extern "C" unsigned long long emu_threshold53(double p) { return mcgp::threshold53(p); }
+extern "C" unsigned long long emu_survival64(double p) { return mcgp::survival64(p); }
 #endif
 
 // The field sizes are spread over EMU_PARTS translation units (compiled in parallel by tests/kernel_host_build.py):

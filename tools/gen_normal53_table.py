@@ -65,6 +65,19 @@ def eval_table(tab, q):
     return z
 
 
+MAX_ABS_ERR = 4e-15                # stated accuracy of the transform: 3.6e-15 measured in the far tail (|z| = 8.2, where an ulp of z is 1.8e-15), 2.7e-15 over random indices; main() asserts it
+
+
+def every_cell_indices(points=9):
+    """Tail indices q that visit every one of the 784 rows: the 16 single-index rows, and `points` places of every cell."""
+    out = list(range(16))
+    for sh in range(48):
+        for k in range(16):
+            lo, width = (16 + k) << sh, 1 << sh
+            out += [lo + min(width - 1, (width * j) // (points - 1)) for j in range(points)]
+    return np.array(sorted(set(out)), dtype=np.uint64)
+
+
 def main():
     tab = rows()
     rng = np.random.default_rng(1)
@@ -76,7 +89,20 @@ def main():
     err = np.abs(z - exact)
     print(f'rows={NROWS} degree={DEG} max abs err={err.max():.3e} max rel err={np.max(err / np.abs(exact)):.3e}',
           file=sys.stderr)
+    # the stated bound is ASSERTED: random indices, the special ones, and every cell at nine points
+    qc = every_cell_indices()
+    cell_err = np.abs(eval_table(tab, qc) - ndtri((qc.astype(np.float64) + 0.5) / 2.0 ** 53))
+    print(f'every cell x 9 points: max abs err={cell_err.max():.3e}', file=sys.stderr)
+    assert max(err.max(), cell_err.max()) <= MAX_ABS_ERR, (err.max(), cell_err.max())
     words = tab.view(np.uint64).reshape(-1)
+    if '--check' in sys.argv[1:]:
+        # regenerate, assert the bound (above) and compare with the committed copies; nothing is written
+        import re
+        for path in ('oracle/normal53_table.h', 'monte_carlo_gp_amd/csrc/normal53_table.h'):
+            with open(os.path.join(ROOT, path)) as f:
+                have = [int(x[:-3], 16) for x in re.findall(r'0x[0-9a-f]{16}ull', f.read())]
+            assert have == [int(x) for x in words], f'{path} is not what this generator writes'
+        return 0
     body = ',\n'.join('  ' + ', '.join(f'0x{x:016x}ull' for x in words[i:i + 4]) for i in range(0, len(words), 4))
     for path, guard, who in (
             ('oracle/normal53_table.h', 'MCGP_ORACLE_NORMAL53_TABLE_H', 'oracle (test infrastructure)'),

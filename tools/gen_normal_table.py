@@ -76,6 +76,22 @@ def eval_table(tab, w):
     return np.where(sign == 1, -z, z), (m + 0.5) / 2.0 ** 32, sign
 
 
+MAX_ABS_ERR = 4.8e-7               # stated accuracy of the transform; main() asserts it
+
+
+def every_cell_words(points=9):
+    """Draw words that visit every one of the 448 cells at `points` places (first, last, evenly spaced between), both signs."""
+    out = []
+    for e in range(4, 32):
+        for k in range(16):
+            lo = (16 + k) << (e - 4)                   # mm = m + 16 at the start of the cell
+            width = 1 << (e - 4)
+            for j in range(points):
+                mm = lo + min(width - 1, (width * j) // (points - 1))
+                out += [mm - 16, (mm - 16) | 0x80000000]
+    return np.array(sorted(set(out)), dtype=np.uint64)
+
+
 def main():
     tab = rows()
     rng = np.random.default_rng(1)
@@ -90,7 +106,22 @@ def main():
     err = np.abs(z - exact)
     print(f'rows={NROWS} max abs err={err.max():.3e} max rel err={np.max(err / np.maximum(np.abs(exact), 1e-3)):.3e}',
           file=sys.stderr)
+    # the bound the documentation states (bench.py dtype_note) is ASSERTED, over random words, the special
+    # words above and every cell of the table at nine points and both signs
+    cells = every_cell_words()
+    zc, pc, sc = eval_table(tab, cells)
+    cell_err = np.abs(zc - np.where(sc == 1, -ndtri(pc), ndtri(pc)))
+    print(f'every cell x 9 points x 2 signs: max abs err={cell_err.max():.3e}', file=sys.stderr)
+    assert max(err.max(), cell_err.max()) <= MAX_ABS_ERR, (err.max(), cell_err.max())
     words = tab.view(np.uint32).reshape(-1)
+    if '--check' in sys.argv[1:]:
+        # regenerate, assert the bound (above) and compare with the committed copies; nothing is written
+        import re
+        for path in ('oracle/normal_table.h', 'monte_carlo_gp_amd/csrc/normal_table.h'):
+            with open(os.path.join(ROOT, path)) as f:
+                have = [int(x[:-1], 16) for x in re.findall(r'0x[0-9a-f]{8}u', f.read())]
+            assert have == [int(x) for x in words], f'{path} is not what this generator writes'
+        return 0
     body = ',\n'.join('  ' + ', '.join(f'0x{x:08x}u' for x in words[i:i + 8]) for i in range(0, len(words), 8))
     for path, guard, who in (
             ('oracle/normal_table.h', 'MCGP_ORACLE_NORMAL_TABLE_H', 'oracle (test infrastructure)'),
