@@ -73,8 +73,8 @@ typedef struct mcgp_config {
      * the product's fast path.  MCGP_DEVIATES_53: the reference's width -- 53-bit uniforms (random.random(),
      * np.random.choice: genrand_res53) and binary64 normals (reference src/simulation.py:137,194,302,330,524) --, every
      * draw keeping the 32-bit mode's word as its leading bits and taking 21 more from a companion Philox block; a
-     * priced option (about twice the Philox work, a binary64 inverse normal), built for field sizes 10, 20 and 21,
-     * MCGP_E_BAD_ARG for the others; mcgp_run / mcgp_run_device / mcgp_simulate_race only. */
+     * priced option (half as many Philox blocks again, a binary64 inverse normal from a table in LDS), built for every
+     * field size; MCGP_E_BAD_ARG for a problem only the generic kernel takes. */
     int32_t deviates;
 } mcgp_config;
 

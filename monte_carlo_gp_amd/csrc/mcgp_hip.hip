@@ -56,15 +56,8 @@ int fail(int code, const std::string &msg)
     X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 #endif
 
-// Field sizes the reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53) is compiled for: those of the golden
-// workloads.  Keep in step with reg_inst.hip.
-#if defined(MCGP_ONLY_N20)
-#define MCGP_WIDE_SIZES(X) X(20)
-#elif defined(MCGP_ONLY_N)
-#define MCGP_WIDE_SIZES(X)
-#else
-#define MCGP_WIDE_SIZES(X) X(10) X(20) X(21)
-#endif
+// The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53) is compiled for the same field sizes (reg_inst.hip).
+#define MCGP_WIDE_SIZES(X) MCGP_REG_SIZES(X)
 
 // Grid-probability front end (reference src/elo.py:124-141, src/predictor.py:321-407): one thread per driver row.
 // in = [rating | teammate_delta | form_score | circuit_affinity], n doubles each.  Thread 0 computes the n pole
@@ -386,8 +379,10 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kerne
     int waves = 1, blocks_per_cu = 1;
     size_t bytes = 0;
     if (is_reg) {
+        // (reg_waves != 0: the reference-width build, whose block also holds rows of the binary64 inverse-normal table)
         waves = reg_waves ? reg_waves : mcgp::reg_block_waves((int)n);
-        bytes = mcgp::shared_lds_bytes_reg((int)n) + (size_t)waves * 64 * mcgp::per_thread_lds_bytes_reg((int)n);
+        bytes = reg_waves ? mcgp::wide_lds_bytes((int)n, reg_waves)
+                          : mcgp::shared_lds_bytes_reg((int)n) + (size_t)waves * 64 * mcgp::per_thread_lds_bytes_reg((int)n);
     } else {
         const size_t per_wave = 64 * mcgp::per_thread_lds_bytes((int)n);
         waves = (int)((c.lds_per_block - mcgp::kSharedTableBytes) / per_wave);
@@ -451,8 +446,8 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     if (kp.wide) {
         wide = select_wide_kernel((uint32_t)kp.n);
         if (!wide || !mcgp::reg_kernel_serves(kp))
-            return fail(MCGP_E_BAD_ARG, "deviates = MCGP_DEVIATES_53 is built for fields of 10, 20 and 21 cars (and problems "
-                                        "the register kernel takes)");
+            return fail(MCGP_E_BAD_ARG, "deviates = MCGP_DEVIATES_53 serves the problems the register kernel takes "
+                                        "(reg_kernel_serves: lap times clear of zero, overtake_delta >= 0)");
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)c.lds_per_block));
         is_reg = true;
@@ -531,7 +526,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     for (uint64_t done = 0; done < n_sims; done += cap) {
         const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
         launch_geometry(c, (uint32_t)kp.n, is_reg, wide ? reinterpret_cast<KernelFn>(wide) : kernel, m, &grid, &block, &lds,
-                        wide ? mcgp::kWideBlockWaves : 0);
+                        wide ? mcgp::wide_block_waves(kp.n) : 0);
         // units of work: the register kernel's waves claim chunks of 64 simulations from the stream's counter, a block
         // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
         const uint64_t unit = is_reg ? 64u : block;

@@ -8,6 +8,8 @@ namespace mcgp {
 
 constexpr int kMaxCars = 32;
 constexpr int kNormalRows = 448;
+constexpr int kNormal53Rows = 784;             // binary64 inverse-normal table of the reference-width build (normal53_table.h)
+constexpr int kNormal53RowBytes = 64;          // 8 coefficients
 constexpr int kCompStride = 8;
 
 // Philox counter word 3 = purpose << 16 | index   (the oracle uses the same map)
@@ -41,15 +43,6 @@ __host__ __device__ inline uint32_t draw_retirement_lap(uint32_t w, uint64_t t, 
     }
     return 0u;
 }
-
-// pk word layout
-constexpr uint32_t kAgeMask = 0x3FFu;          // tyre age; lap of retirement once dnf is set
-constexpr int kCompShift = 10;                 // 3 bits
-constexpr int kUsedShift = 13;                 // 5 bits, one per compound
-constexpr int kGposShift = 18;                 // 5 bits, grid slot
-constexpr uint32_t kDnf = 1u << 23;
-constexpr uint32_t kDrs = 1u << 24;
-constexpr uint32_t kDirty = 1u << 25;          // 0 < time_behind_leader < dirty_air_threshold
 
 // Read-only problem description, resident in device memory, uniform across lanes.
 struct KParams {
@@ -177,6 +170,33 @@ __device__ __forceinline__ double normal53(uint32_t w, uint32_t companion, const
     const uint64_t q = ((uint64_t)(w & 0x7fffffffu) << 21) | (uint64_t)(companion >> 11);
     const double z0 = normal53_tail(q, tab);
     return (w >> 31) ? -z0 : z0;
+}
+// The same transform in three steps, for the hot loop (several deviates: all rows named, then fetched, then evaluated).
+// The row and the cell coordinate come out of the bits of double(q) -- exact, q < 2^52 -- instead of a count-leading-zeros
+// and 64-bit shifts: with e = floor(log2 q) >= 4 the biased exponent and the four leading mantissa bits ARE the row,
+//     row = 16 + 16 (e - 4) + k = (hi word >> 16) - kNormal53HiBias,
+// the other 48 mantissa bits are r left-aligned, so X = 1 + r 2^-sh is the same mantissa moved up by four bits under the
+// exponent of 1.0, and  t = (r + 0.5) 2^-sh = (X - 1) + 2^(3 - e)  (both additions exact: the result is the oracle's
+// ((double)r + 0.5) * 2^-sh, bit for bit).  Tail indices below 16 (rows 0 .. 15, no cell coordinate) are not served here:
+// `hi` below (kNormal53HiBias + 16) << 16 says so, and the caller goes to normal53() above.
+constexpr uint32_t kNormal53HiBias = 16u * 1023u + 48u;        // (hi >> 16) of double(16.0) is 16 x 1027 = bias + 16
+__device__ __forceinline__ void normal53_prepare(uint32_t w, uint32_t companion, uint32_t &hi, double &t)
+{
+    const double D = __builtin_fma((double)(w & 0x7fffffffu), 0x1p21, (double)(companion >> 11));       // = q
+    hi = (uint32_t)__double2hiint(D);
+    const uint32_t lo = (uint32_t)__double2loint(D);
+    const double X = __hiloint2double((int)((((hi << 4) | (lo >> 28)) & 0xFFFFFu) | 0x3FF00000u), (int)(lo << 4));
+    const double H = __hiloint2double((int)(0x80100000u - (hi & 0x7FF00000u)), 0);                        // 2^(3 - e)
+    t = (X - 1.0) + H;
+}
+// (c = the row's eight coefficients)
+__device__ __forceinline__ double normal53_evaluate(uint32_t w, const double (&c)[8], double t)
+{
+    double z = c[7];
+#pragma unroll
+    for (int d = 6; d >= 0; --d) z = __builtin_fma(z, t, c[d]);
+    // z0 = Phi^-1(tail probability) < 0: the sign bit of w flips it
+    return __hiloint2double((int)((uint32_t)__double2hiint(z) ^ (w & 0x80000000u)), __double2loint(z));
 }
 // the 53-bit uniform's numerator q (u = q / 2^53) of a draw
 __device__ __forceinline__ uint64_t uniform53(uint32_t w, uint32_t companion)

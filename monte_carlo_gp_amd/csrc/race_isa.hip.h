@@ -271,20 +271,33 @@ __device__ __forceinline__ void bubble_bwd4(double &c0, uint32_t &p0, double &c1
 // `row` advanced by `stride` for a candidate, so that the W-plane address of a pair's draw word is a running sum over the
 // pairs before it instead of a popcount.  (STRIDE is an assembly-time literal: a register holding it would be one more
 // value alive across the whole pass.)
-template <uint32_t STRIDE>
+// CEIL = false (the reference-width build): thr = min(floor(dl), 2^31) -- the conversion truncates by itself.
+template <uint32_t STRIDE, bool CEIL = true>
 __device__ __forceinline__ void ovt_threshold(double dl, double od, uint32_t row, uint32_t &thr, uint32_t &next)
 {
-    double t;
-    asm("v_cmp_lt_f64 vcc, %[od], %[dl]\n\t"
-        "v_ceil_f64 %[t], %[dl]\n\t"
-        "v_cvt_u32_f64 %[thr], %[t]\n\t"
-        "v_min_u32 %[thr], 0x80000000, %[thr]\n\t"
-        "v_add_u32 %[next], %[stride], %[row]\n\t"
-        "v_cndmask_b32 %[thr], 0, %[thr], vcc\n\t"
-        "v_cndmask_b32 %[next], %[row], %[next], vcc"
-        : [t] "=&v"(t), [thr] "=&v"(thr), [next] "=&v"(next)
-        : [dl] "v"(dl), [od] "s"(od), [row] "v"(row), [stride] "n"(STRIDE)
-        : "vcc");
+    if constexpr (CEIL) {
+        double t;
+        asm("v_cmp_lt_f64 vcc, %[od], %[dl]\n\t"
+            "v_ceil_f64 %[t], %[dl]\n\t"
+            "v_cvt_u32_f64 %[thr], %[t]\n\t"
+            "v_min_u32 %[thr], 0x80000000, %[thr]\n\t"
+            "v_add_u32 %[next], %[stride], %[row]\n\t"
+            "v_cndmask_b32 %[thr], 0, %[thr], vcc\n\t"
+            "v_cndmask_b32 %[next], %[row], %[next], vcc"
+            : [t] "=&v"(t), [thr] "=&v"(thr), [next] "=&v"(next)
+            : [dl] "v"(dl), [od] "s"(od), [row] "v"(row), [stride] "n"(STRIDE)
+            : "vcc");
+    } else {
+        asm("v_cmp_lt_f64 vcc, %[od], %[dl]\n\t"
+            "v_cvt_u32_f64 %[thr], %[dl]\n\t"
+            "v_add_u32 %[next], %[stride], %[row]\n\t"
+            "v_min_u32 %[thr], 0x80000000, %[thr]\n\t"
+            "v_cndmask_b32 %[next], %[row], %[next], vcc\n\t"
+            "v_cndmask_b32 %[thr], 0, %[thr], vcc"
+            : [thr] "=&v"(thr), [next] "=&v"(next)
+            : [dl] "v"(dl), [od] "s"(od), [row] "v"(row), [stride] "n"(STRIDE)
+            : "vcc");
+    }
 }
 
 // LDS access by ABSOLUTE byte address.  The register kernel declares no static __shared__ data, so its

@@ -29,6 +29,16 @@
 
 namespace mcgp {
 
+// pk word of THIS kernel (the register kernel has its own layout: k3* in race_kernel_reg.hip.h)
+constexpr uint32_t kAgeMask = 0x3FFu;          // tyre age; lap of retirement once dnf is set
+constexpr int kCompShift = 10;                 // 3 bits
+constexpr int kUsedShift = 13;                 // 5 bits, one per compound
+constexpr int kGposShift = 18;                 // 5 bits, grid slot
+constexpr uint32_t kDnf = 1u << 23;
+constexpr uint32_t kDrs = 1u << 24;
+constexpr uint32_t kDirty = 1u << 25;          // 0 < time_behind_leader < dirty_air_threshold
+
+
 // Per-lane view of the LDS rows.
 struct Rows {
     double *cum;

@@ -59,6 +59,18 @@
 #ifndef MCGP_COOPERATIVE_EVENTS
 #define MCGP_COOPERATIVE_EVENTS 1
 #endif
+// Diagnostic (host build, tests): 1 = the reference-width build takes its exact 53-bit path for every event draw and every
+// overtake pass (the path a wave otherwise takes for one draw in 2^32: a word equal to the leading word of its threshold),
+// and reads the table row of every deviate from device memory (the path of a row the block does not hold in LDS).
+#ifndef MCGP_WIDE_EXACT
+#define MCGP_WIDE_EXACT 0
+#endif
+// Diagnostic: a draw word counts as "equal to the leading word of its threshold" when the two agree in all but their
+// lowest MCGP_WIDE_TIE_SHIFT bits (0 in the product: equality).  A wider net sends a share of the waves down the exact
+// path with only SOME of their lanes needing it -- the mix a real tie produces, at a rate a test can see.
+#ifndef MCGP_WIDE_TIE_SHIFT
+#define MCGP_WIDE_TIE_SHIFT 0
+#endif
 
 namespace mcgp {
 
@@ -142,11 +154,34 @@ __host__ __device__ constexpr int reg_block_waves(int n)
 __host__ __device__ constexpr size_t reg_retire_ws_bytes(int n, size_t lanes) { return (size_t)(n + 1) * lanes * 4; }
 
 // (WAVES: the default is the block shape measured best for the field size; the reference-width build runs at 2 waves per
-//  SIMD -- 256 registers instead of 168, which its 64-bit thresholds and binary64 deviates want -- in blocks of 8 waves)
+//  SIMD -- 256 registers instead of 168, which its binary64 deviates want -- in blocks of 8 waves)
 constexpr int kWideBlockWaves = 8;
-template <int N, int WAVES = reg_block_waves(N)>
+// The reference-width build keeps the binary64 inverse-normal table (normal53_table.h: 784 rows of 8 coefficients, 64 B
+// each) in LDS, behind the per-lane planes, instead of the 7 KB binary32 table it has no use for: as many of the table's
+// LAST rows -- the cells of the largest tail indices -- as fit beside the block's other data, in whole octaves of 16 rows,
+// and at most kWideLdsRowsMax of them: every octave left out halves the share of deviates that go to the copy in device
+// memory instead (normal53_rows, race_common.hip.h), which at 2^-32 per draw (a few wave-batches per 10^7 races) costs
+// nothing and keeps that path exercised.
+constexpr int kWideLdsRowsMax = 32 * 16;
+__host__ __device__ constexpr size_t wide_fixed_lds_bytes(int n, int waves)
+{
+    return shared_lds_bytes_reg(n) - (size_t)kNormalRows * 16 + (size_t)waves * 64 * per_thread_lds_bytes_reg(n);
+}
+__host__ __device__ constexpr int wide_lds_rows(int n, int waves)
+{
+    const size_t fixed = wide_fixed_lds_bytes(n, waves);
+    const size_t room = kLdsPerCu - kLdsReserve > fixed ? kLdsPerCu - kLdsReserve - fixed : 0;
+    int rows = (int)(room / (size_t)kNormal53RowBytes) / 16 * 16;
+    return rows > kWideLdsRowsMax ? kWideLdsRowsMax : rows;
+}
+__host__ __device__ constexpr size_t wide_lds_bytes(int n, int waves)
+{
+    return wide_fixed_lds_bytes(n, waves) + (size_t)wide_lds_rows(n, waves) * kNormal53RowBytes;
+}
+template <int N, int WAVES = reg_block_waves(N), bool WIDE = false>
 struct RegGeo {
     static constexpr int kWaves = WAVES;
+    static constexpr bool kWide = WIDE;
     static constexpr int B = 64 * kWaves;                         // threads per block
     // block-shared tables first: their bases (and the row bases below) fit the 16-bit immediate offset of a DS
     // instruction, so an address is just the bit field taken from pk
@@ -158,19 +193,33 @@ struct RegGeo {
     static constexpr uint32_t oPit = oDrs + 16;                   // {0.0, pit_loss}                           (the stop's time, by flag)
     static constexpr uint32_t oDrsB = oDrs + 32;                  // {0.0, drs_delta 2^31}                     (overtake pace)
     static constexpr uint32_t oLut = oDrsB + 32;                  // pit rule: u32 [4 regimes][8 used-sets]
-    static constexpr uint32_t oNorm = oLut + 128;                 // float4[kNormalRows]; addressed from kNormalRowBias rows before it
-    static constexpr uint32_t oHist = oNorm + kNormalRows * 16;   // u32[N x N]
-    static_assert(oNorm >= kNormalRowBias * 16, "the inverse-normal rows are addressed through a base 48 rows before the table");
+    static constexpr uint32_t oNorm = oLut + 128;                 // float4[kNormalRows]; addressed from kNormalRowBias rows before it (not WIDE)
+    static constexpr uint32_t oHist = oNorm + (WIDE ? 0 : kNormalRows * 16);   // u32[N x N]
+    static_assert(WIDE || oNorm >= kNormalRowBias * 16, "the inverse-normal rows are addressed through a base 48 rows before the table");
     static constexpr uint32_t oGrid = oHist + (uint32_t)align16((size_t)N * N * 4);   // f64 [slot][driver]
     static constexpr uint32_t oW = oGrid + (uint32_t)align16((size_t)N * N * 8);   // [kWordRows][B] u32, 16-byte aligned (odd N: padded)
     static constexpr uint32_t oLast = oW + (uint32_t)kWordRows * B * 4;      // [N][B] f64
-    static constexpr uint32_t kBytes = oLast + (uint32_t)N * B * 8;
-    static_assert(oW == shared_lds_bytes_reg(N) && oLast % 8 == 0, "LDS map");
-    static_assert(oW % 16 == 0, "the event handler parks fields with 16-byte LDS accesses (ds_write_b128 / ds_read_b128)");
-    static_assert(kBytes == per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N), "LDS map");
+    // WIDE: rows kNorm53First .. 783 of the binary64 inverse-normal table, 64 B each, behind the per-lane planes
+    static constexpr uint32_t oNorm53 = oLast + (uint32_t)N * B * 8;
+    static constexpr int kNorm53Rows = WIDE ? wide_lds_rows(N, WAVES) : 0;
+    static constexpr int kNorm53First = kNormal53Rows - kNorm53Rows;
+    static constexpr uint32_t kBytes = oNorm53 + (uint32_t)kNorm53Rows * (uint32_t)kNormal53RowBytes;
+    static_assert(oW == shared_lds_bytes_reg(N) - (WIDE ? (size_t)kNormalRows * 16 : 0) && oLast % 8 == 0, "LDS map");
+    static_assert(oW % 16 == 0 && oNorm53 % 16 == 0, "the event handler parks fields with 16-byte LDS accesses (ds_write_b128 / ds_read_b128); table rows are read 16 bytes at a time");
+    static_assert(kBytes == (WIDE ? wide_lds_bytes(N, WAVES) : per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N)), "LDS map");
     static_assert(kBytes + kLdsReserve <= kLdsPerCu, "block does not fit LDS");
     static_assert(oLast < 65536, "row bases must fit the DS immediate offset");
 };
+// waves per block of the reference-width build: 8 (one block per CU at 2 waves per SIMD) where the block's rows fit the
+// CU's LDS, fewer for the largest fields (31 cars and more)
+__host__ __device__ constexpr int wide_block_waves(int n)
+{
+    int w = kWideBlockWaves;
+    while (w > 1 && wide_fixed_lds_bytes(n, w) + kLdsReserve > kLdsPerCu) --w;
+    return w;
+}
+template <int N>
+using WideGeo = RegGeo<N, wide_block_waves(N), true>;
 
 // The sorting network of the full sort: Knuth, TAOCP 5.2.2 Algorithm M (merge exchange) for any N, or, for the sizes
 // listed in sort_networks.h, two size-optimal half sorters and Batcher's odd-even merge (20 cars: 93 comparators instead
@@ -524,14 +573,21 @@ __host__ __device__ inline bool reg_kernel_serves(const KParams &kp)
 
 // Phase 1 of a block: fill the block-shared LDS tables (all threads, strided).
 template <int N, class G = RegGeo<N>>
-__device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid)
+__device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, unsigned char *smem, uint32_t tid,
+                                                const double *__restrict__ norm53 = nullptr)
 {
     constexpr int B = G::B;
-    float4 *t_norm = reinterpret_cast<float4 *>(smem + G::oNorm);
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + G::oHist);
     double *t_grid = reinterpret_cast<double *>(smem + G::oGrid);          // [slot][driver]
-    for (uint32_t i = tid; i < (uint32_t)kNormalRows * 4; i += B)
-        reinterpret_cast<uint32_t *>(t_norm)[i] = P->normal_bits[i];
+    if constexpr (G::kWide) {
+        // the rows of the binary64 inverse-normal table this block keeps in LDS (RegGeo: the table's last kNorm53Rows)
+        double *t53 = reinterpret_cast<double *>(smem + G::oNorm53);
+        for (uint32_t i = tid; i < (uint32_t)G::kNorm53Rows * 8u; i += B) t53[i] = norm53[(uint32_t)G::kNorm53First * 8u + i];
+    } else {
+        float4 *t_norm = reinterpret_cast<float4 *>(smem + G::oNorm);
+        for (uint32_t i = tid; i < (uint32_t)kNormalRows * 4; i += B)
+            reinterpret_cast<uint32_t *>(t_norm)[i] = P->normal_bits[i];
+    }
     for (uint32_t d = tid; d < (uint32_t)N; d += B) {
         double *a = reinterpret_cast<double *>(smem + G::oDrvA + d * 16);
         double *b = reinterpret_cast<double *>(smem + G::oDrvB + d * 16);
@@ -624,6 +680,28 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     // ... and the byte of grid slot `pos` in the W plane (the sampled grid, before lap 1)
     auto grid_byte = [&](int pos) -> uint32_t { return G::oW + (uint32_t)(pos >> 2) * (B * 4) + tid4 + (uint32_t)(pos & 3); };
     auto norm_row = [&](uint32_t off) -> float4 { return lds_ld_float4(G::oNorm - kNormalRowBias * 16u + off); };
+    // WIDE: the binary64 deviate of a draw from the table rows in LDS (normal53_prepare / normal53_evaluate, race_common.hip.h).
+    // `hi` (the leading word of double(q)) names the row; a row the block does not hold -- the cells of the smallest tail
+    // indices, RegGeo::kNorm53First -- is flagged by hi < kRareHi and read from the table in device memory (normal53()).
+    constexpr uint32_t kRareHi = (kNormal53HiBias + (uint32_t)(G::kNorm53First > 16 ? G::kNorm53First : 16)) << 16;
+    [[maybe_unused]] auto norm53_row = [&](uint32_t hi, double (&c)[8]) {
+        const uint32_t a = ((hi >> 10) & ~63u) + (G::oNorm53 - (kNormal53HiBias + (uint32_t)G::kNorm53First) * 64u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f64x2 v = lds_ld_f64x2(a + 16u * k);
+            c[2 * k] = v.x;
+            c[2 * k + 1] = v.y;
+        }
+    };
+    [[maybe_unused]] auto normal53_one = [&](uint32_t w, uint32_t x) -> double {
+        uint32_t hi;
+        double t;
+        normal53_prepare(w, x, hi, t);
+        if (__builtin_expect(MCGP_ANY(G::kNorm53Rows == 0 || MCGP_WIDE_EXACT || hi < kRareHi), 0)) return normal53(w, x, norm53);
+        double c[8];
+        norm53_row(hi, c);
+        return normal53_evaluate(w, c, t);
+    };
 
     const double dirty_thr = P->dirty_thr;                     // (lap 1; the lap loop reads its constants per lap)
     const float kNaN = __uint_as_float(0x7fc00000u);
@@ -786,7 +864,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
                 philox4x32_10(c0, c1, 1u, kPurposeCar | kCompanion | (uint32_t)d, seed_lo, seed_hi, x0, x1, x2, x3);
                 const bool out = uniform53(w0, x0) < P->t53_dnf1[d];
-                lds_st<double>(l_row(d), out ? __builtin_nan("") : normal53(w1, x1, norm53));
+                lds_st<double>(l_row(d), out ? __builtin_nan("") : normal53_one(w1, x1));
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -811,7 +889,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 uint32_t w0, w1, w2, w3, x0, x1, x2, x3;
                 philox4x32_10(c0, c1, 1u, kPurposeCar | (uint32_t)d, seed_lo, seed_hi, w0, w1, w2, w3);
                 philox4x32_10(c0, c1, 1u, kPurposeCar | kCompanion | (uint32_t)d, seed_lo, seed_hi, x0, x1, x2, x3);
-                lds_st<double>(l_row(d), normal53(w2, x2, norm53));
+                lds_st<double>(l_row(d), normal53_one(w2, x2));
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -1022,19 +1100,46 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
             {
                 uint32_t e0, e1, e2, e3;
                 philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent, k0l, k1l, e0, e1, e2, e3);
-                uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-                if constexpr (WIDE) philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent | kCompanion, k0l, k1l, f0, f1, f2, f3);
                 if (MCGP_DUP & 16) {
                     uint32_t f0, f1, f2, f3;
                     philox4x32_10(c0l ^ e0, c1l, (uint32_t)lap, kPurposeEvent, k0l, k1l, f0, f1, f2, f3);
                     if ((f0 | f1 | f2 | f3) == 0u) e0 = f0;     // never true in practice; keeps the block alive
                 }
-                // (the draw's numerator: the 32-bit word, or the word followed by 21 bits of its companion)
-                const uint64_t u_red = WIDE ? uniform53(e0, f0) : (uint64_t)e0, u_sc = WIDE ? uniform53(e1, f1) : (uint64_t)e1,
-                               u_vsc = WIDE ? uniform53(e2, f2) : (uint64_t)e2, u_tire = WIDE ? uniform53(e3, f3) : (uint64_t)e3;
-                const bool red = u_red < t_red;
-                const bool sc = !red && u_sc < t_sc;
-                const bool vsc = !red && !sc && u_vsc < t_vsc;
+                // the lap's four Bernoulli draws (:168, :171, :174, :392)
+                bool d_red, d_sc, d_vsc, d_tire;
+                if constexpr (WIDE) {
+                    // 53-bit numerator q = w 2^21 + (21 bits of the companion word) against T = ceil(p 2^53): the word alone
+                    // decides -- q < T iff w < T >> 21 -- unless w == T >> 21, one draw in 2^32.  The companion block is
+                    // computed only for a wave with such a draw.  (T = 2^53, p >= 1: every word is below.)
+                    const uint32_t h_red = (uint32_t)(t_red >> 21), h_sc = (uint32_t)(t_sc >> 21), h_vsc = (uint32_t)(t_vsc >> 21),
+                                   h_tire = (uint32_t)(t_vsc_tire >> 21);
+                    const bool a_red = (t_red >> 53) != 0, a_sc = (t_sc >> 53) != 0, a_vsc = (t_vsc >> 53) != 0,
+                               a_tire = (t_vsc_tire >> 53) != 0;
+                    auto near = [](uint32_t w, uint32_t h) { return ((w ^ h) >> MCGP_WIDE_TIE_SHIFT) == 0u; };
+                    const bool tie = (!a_red && near(e0, h_red)) || (!a_sc && near(e1, h_sc)) || (!a_vsc && near(e2, h_vsc)) ||
+                                     (!a_tire && near(e3, h_tire));
+                    if (__builtin_expect(!MCGP_ANY(tie || MCGP_WIDE_EXACT), 1)) {
+                        d_red = a_red || e0 < h_red;
+                        d_sc = a_sc || e1 < h_sc;
+                        d_vsc = a_vsc || e2 < h_vsc;
+                        d_tire = a_tire || e3 < h_tire;
+                    } else {
+                        uint32_t f0, f1, f2, f3;
+                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeEvent | kCompanion, k0l, k1l, f0, f1, f2, f3);
+                        d_red = uniform53(e0, f0) < t_red;
+                        d_sc = uniform53(e1, f1) < t_sc;
+                        d_vsc = uniform53(e2, f2) < t_vsc;
+                        d_tire = uniform53(e3, f3) < t_vsc_tire;
+                    }
+                } else {
+                    d_red = (uint64_t)e0 < t_red;
+                    d_sc = (uint64_t)e1 < t_sc;
+                    d_vsc = (uint64_t)e2 < t_vsc;
+                    d_tire = (uint64_t)e3 < t_vsc_tire;
+                }
+                const bool red = d_red;
+                const bool sc = !red && d_sc;
+                const bool vsc = !red && !sc && d_vsc;
                 MCGP_STAT(12, red || sc || vsc);
 #if MCGP_COOPERATIVE_EVENTS
                 // An event is rare per simulation (2.7 % of laps on the benchmark fields) but not per wave: 83 % of
@@ -1057,7 +1162,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     pin(tid_e);
                     const uint32_t lane = tid_e & 63u;
                     const uint32_t wbase = G::oW + ((tid_e * 4u) & ~255u);      // this wave's 256-byte window of row 0
-                    const bool dec_age = sc || (vsc && u_tire < t_vsc_tire);
+                    const bool dec_age = sc || (vsc && d_tire);
                     const uint32_t flags = (red ? 1u : 0u) | (vsc ? 4u : 0u) | (dec_age ? 8u : 0u);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     const uint32_t red_bits = (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
@@ -1162,7 +1267,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     // leader (red flag 0.1 s apart, safety car 0.5 s apart, VSC gaps x 0.8), their time_behind_leader
                     // -- kept as the dirty-air flag -- follows, tyres age one lap less (SC; VSC with probability 0.3)
                     // or are changed (red flag).  Retired cars are left alone.
-                    const bool dec_age = sc || (vsc && u_tire < t_vsc_tire);
+                    const bool dec_age = sc || (vsc && d_tire);
                     const uint32_t newc = stint_compound(track, remaining_laps);
                     const uint32_t red_bits = (newc << k3CompShift) | ((1u << newc) & k3UsedMask);
                     const uint32_t dec_unit = dec_age ? (1u << k3AgeShift) : 0u;
@@ -1261,9 +1366,32 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     using Deviate = std::conditional_t<WIDE, double, float>;
                     Deviate z[MCGP_STEP_BATCH];
                     if constexpr (WIDE) {
+                        // rows named for the whole batch, then fetched (4 x ds_read_b128 each), then evaluated; a batch with
+                        // a deviate whose row is not in LDS (kRareHi) reads all its rows from device memory instead
+                        uint32_t zhi[MCGP_STEP_BATCH];
+                        double zt[MCGP_STEP_BATCH];
+                        bool rare = G::kNorm53Rows == 0 || MCGP_WIDE_EXACT;
 #pragma unroll
-                        for (int j = 0; j < MCGP_STEP_BATCH; ++j)
-                            z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
+                        for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
+                            normal53_prepare(w[j >> 2][j & 3], x[j >> 2][j & 3], zhi[j], zt[j]);
+                            rare |= (i0 + j < N) && zhi[j] < kRareHi;
+                        }
+                        MCGP_STAT(15, rare);
+                        if (__builtin_expect(!MCGP_ANY(rare), 1)) {
+#pragma unroll
+                            for (int j0 = 0; j0 < MCGP_STEP_BATCH; j0 += 2) {
+                                double zc[2][8];
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) norm53_row(zhi[j0 + j], zc[j]);
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    z[j0 + j] = (i0 + j0 + j < N) ? normal53_evaluate(w[(j0 + j) >> 2][(j0 + j) & 3], zc[j], zt[j0 + j]) : 0.0;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < MCGP_STEP_BATCH; ++j)
+                                z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
+                        }
                     } else {
                         // two table rows are fetched at a time, then evaluated (half the LDS round trips in a row; four at a
                         // time cost sixteen registers the loop does not have)
@@ -1353,12 +1481,17 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // -- one integer per pair instead of a binary64 delta kept across the draw-word generation.
                 uint32_t thr[N];
                 uint32_t ow[N];                  // ow[i] = the draw word of the attempt at pair i
-                uint32_t hits53 = 0u;            // (WIDE) bit i: the attempt at pair i succeeds
                 uint32_t n_attempts = 0u;        // (statistics of the host build)
-                if constexpr (WIDE) {
-                    // Reference-width draws: u < min(0.5, delta / 2) for u = q / 2^53 is q < min(ceil(delta 2^52), 2^52); the
-                    // pace deltas carry 2^31, so the threshold is min(ceil(dl 2^21), 2^52).  Plain code, four attempts at
-                    // a time: their words in rows 0..3 of the W plane, the companion words in rows 4..7.
+                // WIDE (reference-width draws): u < min(0.5, delta / 2) for u = q / 2^53, q = w 2^21 + (21 bits of the companion
+                // word), is  q < T = min(ceil(dl 2^21), 2^52)  (the pace deltas carry 2^31).  T lies in [floor(dl) 2^21,
+                // (floor(dl) + 1) 2^21], so the draw's word alone decides -- a success iff w < floor(dl), none iff w > floor(dl)
+                // -- unless w == floor(dl), one attempt in 2^32: the pass runs the default code with thr = min(floor(dl), 2^31)
+                // (ovt_threshold without the ceiling), and a wave with such an attempt (or with more than eight attempts in
+                // a lane) decides the whole pass with the exact 53-bit code below, companion blocks and all.
+                [[maybe_unused]] auto wide_pass_exact = [&]() -> uint32_t {
+                    // Plain code, four attempts at a time: their words in rows 0..3 of the W plane, the companion words
+                    // in rows 4..7.  Returns bit i = the attempt at pair i succeeds.
+                    uint32_t hits53 = 0u;
                     uint64_t thr64[N];
                     uint32_t cand = 0u;
                     {
@@ -1381,8 +1514,6 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                             pace_prev = pace;
                         }
                     }
-                    MCGP_STAT(0 + pass, cand != 0u);
-                    if (cand == 0u) break;
                     uint32_t rest = cand;
 #pragma unroll 1
                     for (int chunk = 0; MCGP_ANY(rest != 0u); ++chunk) {
@@ -1412,8 +1543,9 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         hits53 |= h & cur;
                         rest = m;
                     }
-                    n_attempts = (uint32_t)__popc(cand);
-                } else {
+                    return hits53;
+                };
+                {
                     // ---- overtakes: draw words ----
                     // the k-th attempt of this pass reads word k & 3 of block 8 * pass + k / 4.  The first eight -- all that
                     // all but a few wave-passes in a thousand need -- are drawn FIRST, into the eight rows of the W plane: the
@@ -1463,7 +1595,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                         const double dl = (pace_prev - pace) + pa[j];                   // :516, :519-520 (x 2^31)
                                         // candidate iff dl > overtake_delta (:522); threshold min(ceil(dl), 2^31) (:523-524)
                                         uint32_t next;
-                                        ovt_threshold<(uint32_t)(B * 4)>(dl, od31, row, thr[i], next);
+                                        ovt_threshold<(uint32_t)(B * 4), !WIDE>(dl, od31, row, thr[i], next);
                                         // (a pair that is no candidate fetches the word of the next attempt, or one just past
                                         //  the plane: its threshold is 0)
                                         ow[i] = lds_ld<uint32_t>(G::oW + row);
@@ -1482,7 +1614,20 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     n_attempts = words_end / (uint32_t)(B * 4);
                     // A wave with a lane that has more than eight attempts takes the general path, 8 attempts at a time, and
                     // leaves its verdicts in the same two arrays (ow = 0, thr = 1 for a success).
-                    if (__builtin_expect(MCGP_ANY(words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
+                    if constexpr (WIDE) {
+                        bool tie = false;
+#pragma unroll
+                        for (int i = 1; i < N; ++i) tie |= ((ow[i] ^ thr[i]) >> MCGP_WIDE_TIE_SHIFT) == 0u;
+                        MCGP_STAT(11, tie);
+                        if (__builtin_expect(MCGP_ANY(tie || MCGP_WIDE_EXACT || words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
+                            const uint32_t hits = wide_pass_exact();
+#pragma unroll
+                            for (int i = 1; i < N; ++i) {
+                                thr[i] = (hits >> i) & 1u;
+                                ow[i] = 0u;
+                            }
+                        }
+                    } else if (__builtin_expect(MCGP_ANY(words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
                         // the candidate mask: a candidate's threshold is at least 1 (dl > overtake_delta >= 0: reg_kernel_serves
                         // sends a negative delta -- attempts at a pace DEFICIT -- to the generic kernel)
                         uint32_t cand = 0u;
@@ -1528,7 +1673,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 bool any_succ = false;
 #pragma unroll
                 for (int i = 1; i < N; ++i) {
-                    const bool hit = WIDE ? ((hits53 >> i) & 1u) != 0u : ow[i] < thr[i];
+                    const bool hit = ow[i] < thr[i];
                     const double nb = cum[i - 1] - 0.1;                        // max(0.1, ahead - 0.1), :528: reg_time_floor()
                     const double na = nb + 0.3;                                // :530
                     cum[i] = hit ? nb : cum[i];
@@ -1622,16 +1767,16 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
 
 // The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): same phases, blocks of 8 waves at 2 waves per SIMD.
 template <int N>
-__global__ void __launch_bounds__((RegGeo<N, kWideBlockWaves>::B), 2)
+__global__ void __launch_bounds__((WideGeo<N>::B), 2)
 race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                      uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                      uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,
                      uint32_t *__restrict__ ticket, uint32_t *__restrict__ retire_ws, const double *__restrict__ norm53)
 {
-    using G = RegGeo<N, kWideBlockWaves>;
+    using G = WideGeo<N>;
     extern __shared__ __align__(16) unsigned char smem[];
     if ((int)blockDim.x != G::B || lds_base_of(smem) != 0u) __builtin_trap();
-    reg_load_tables<N, G>(P, smem, threadIdx.x);
+    reg_load_tables<N, G>(P, smem, threadIdx.x, norm53);
     __syncthreads();
     reg_simulate<N, true, G>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
                              retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B), norm53);

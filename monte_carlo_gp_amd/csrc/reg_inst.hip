@@ -12,10 +12,8 @@ template __global__ void race_kernel_reg<MCGP_INST_N>(const KParams *, uint64_t,
                                                       unsigned long long *, uint8_t *, const uint8_t *, uint32_t, uint32_t *, uint32_t *);
 template __global__ void race_kernel_reg_batch<MCGP_INST_N>(const KParams *, const BatchItem *, uint32_t, uint64_t,
                                                             unsigned long long *, uint32_t, uint32_t *, uint32_t *);
-// the reference-width build exists for the field sizes of the golden workloads (keep in step with MCGP_WIDE_SIZES, mcgp_hip.hip)
-#if MCGP_INST_N == 10 || MCGP_INST_N == 20 || MCGP_INST_N == 21
+// the reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53)
 template __global__ void race_kernel_reg_wide<MCGP_INST_N>(const KParams *, uint64_t, uint64_t, uint32_t, uint32_t,
                                                            unsigned long long *, uint8_t *, const uint8_t *, uint32_t, uint32_t *,
                                                            uint32_t *, const double *);
-#endif
 }  // namespace mcgp

@@ -112,8 +112,8 @@ class RaceSimulator:
     def __init__(self, config: RaceConfig, device=0, set_pop: dict | None = None, deviates: int = 32):
         """`deviates`: 32 (default) -- uniforms w / 2^32 and normals from a binary32 cubic table, the fast path -- or 53:
         the reference's width, 53-bit uniforms and binary64 normals (reference :137,194,302,330,524), every draw keeping
-        the 32-bit mode's word as its leading bits; a priced option (include/mcgp.h: mcgp_config.deviates), built for
-        fields of 10, 20 and 21 cars.
+        the 32-bit mode's word as its leading bits; a priced option (include/mcgp.h: mcgp_config.deviates), every field
+        size.
 
         `device`: a HIP device index (default 0), a list of indices, or 'all' (every visible device).  With more
         than one device a run_monte_carlo call is split by simulation id into contiguous shards, one host thread per

@@ -18,6 +18,11 @@ _libs = {}
 VARIANTS = {
     None: [],
     'grid_exact': ['-DMCGP_GRID_EXACT=1'],      # _sample_grid takes the exact (dividing) path for every draw
+    # the reference-width build decides every event draw and overtake pass with its exact 53-bit code (the path of a draw
+    # word equal to the leading word of its threshold, one in 2^32), and reads every deviate's row from device memory
+    'wide_exact': ['-DMCGP_WIDE_EXACT=1'],
+    # ... a draw word within 2^27 of the leading word of its threshold counts as a tie: a few per cent of the draws
+    'wide_near_ties': ['-DMCGP_WIDE_TIE_SHIFT=27'],
 }
 
 
@@ -25,7 +30,7 @@ def build(variant=None):
     LIB = os.path.join(EMU_DIR, 'libmcgp_emu.so' if variant is None else f'libmcgp_emu_{variant}.so')
     tag = '' if variant is None else '_' + variant
     srcs = [os.path.join(EMU_DIR, f) for f in ('emu_kernel.cpp', 'race_isa_host.h', 'hip/hip_runtime.h')]
-    srcs += [os.path.join(CSRC, f) for f in ('race_kernel_reg.hip.h', 'race_common.hip.h', 'params_build.h', 'normal_table.h', 'sort_networks.h')]
+    srcs += [os.path.join(CSRC, f) for f in ('race_kernel_reg.hip.h', 'race_common.hip.h', 'params_build.h', 'normal_table.h', 'normal53_table.h', 'sort_networks.h')]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         # four translation units (field sizes n % 4 == k) compiled side by side, then linked
         flags = ['-O1', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-I' + EMU_DIR, '-DEMU_PARTS=4']

@@ -45,15 +45,15 @@ def test_fuzzed_configurations_match_oracle(require_gpu, monkeypatch):
 
 
 def test_fuzzed_configurations_at_reference_width(require_gpu):
-    """deviates = 53 against the oracle's PHILOX53 back-end on every fuzz configuration of a field size the wide build
-    exists for (10, 20, 21 cars: 34 configurations, the corner cases among them -- everybody retiring, events on
-    every lap, a pit stop every lap, one-lap races)."""
+    """deviates = 53 against the oracle's PHILOX53 back-end on every fuzz configuration the register kernel takes, whatever
+    its field size (the corner cases among them -- everybody retiring, events on every lap, a pit stop every lap,
+    one-lap races)."""
     from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N
     with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
         cases = json.load(f)
     done = 0
     for name, c in cases.items():
-        if len(c['grid_probs']) not in (10, 20, 21) or c['config']['overtake_delta'] < 0:
+        if c['config']['overtake_delta'] < 0:
             continue
         ref = O.Problem(c).run(800, rng=O.RNG_PHILOX53, seed=c['seed'], want_orders=True)
         sim = RaceSimulator(RaceConfig(**c['config']), set_pop=O.load_cases()['set_pop'], deviates=53)
@@ -65,7 +65,7 @@ def test_fuzzed_configurations_at_reference_width(require_gpu):
         assert bad.size == 0, f'{name}: {bad.size} finishing orders differ, first {bad[:5]}'
         assert np.array_equal(sim.last_histogram, ref['hist']), name
         done += 1
-    assert done >= 30
+    assert done >= 80
 
 
 def test_fuzzed_configurations_in_one_batch_launch(require_gpu):

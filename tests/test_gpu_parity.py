@@ -53,10 +53,8 @@ def test_generic_and_register_kernels_agree(require_gpu, monkeypatch):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 7, 9, 17, 18, 19, 22, 24, 25, 26, 32])
-def test_other_field_sizes(require_gpu, n):
-    """Field sizes beyond the golden cases (generic LDS kernel and further register instantiations),
-    up to the ABI maximum, with an all-zero grid column (Q18 uniform fallback)."""
+def _field(n):
+    """An n-car field with S60's parameters, 25 laps and an all-zero grid column (Q18 uniform fallback)."""
     rng = np.random.default_rng(n)
     drivers = [f'D{i:02d}' for i in range(n)]
     base = O.load_case('S60')
@@ -70,6 +68,14 @@ def test_other_field_sizes(require_gpu, n):
     case['tire_deg'] = {d: 0.05 for d in drivers}
     case['driver_variance'] = {d: 0.2 for d in drivers}
     case['driver_dnf_rates'] = {d: 0.01 for d in drivers}
+    return case
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 9, 17, 18, 19, 22, 24, 25, 26, 32])
+def test_other_field_sizes(require_gpu, n):
+    """Field sizes beyond the golden cases (generic LDS kernel and further register instantiations),
+    up to the ABI maximum, with an all-zero grid column (Q18 uniform fallback)."""
+    case = _field(n)
     hist, probs, orders = product_run(case, 1000, 5, orders=True)
     ref = O.Problem(case).run(1000, rng=O.RNG_PHILOX, seed=5, want_orders=True)
     assert np.array_equal(orders, ref['orders'])
@@ -443,17 +449,32 @@ def test_reference_width_deviates_match_the_oracle(require_gpu, name):
     assert np.array_equal(sim.last_histogram, ref['hist'])
 
 
-def test_reference_width_deviates_are_built_for_three_field_sizes(require_gpu):
+def test_reference_width_deviates_at_every_field_size(require_gpu):
+    """deviates = 53 is built for every field size (19-22-car sessions; the sizes whose blocks hold all /
+    some / none of the binary64 table rows in LDS: RegGeo::kNorm53Rows); a problem only the generic kernel takes is
+    refused with MCGP_E_BAD_ARG, a width other than 32 / 53 with ValueError."""
+    import copy
     from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N
     case = O.load_case('S60')
-    keep = list(case['grid_probs'])[:7]
-    sub = {k: {d: (v[:7] if k == 'grid_probs' else v) for d, v in case[k].items() if d in keep}
-           for k in ('grid_probs', 'base_pace', 'tire_deg', 'driver_variance', 'driver_dnf_rates')}
-    sim = RaceSimulator(RaceConfig(**case['config']), deviates=53)
+    for n in (1, 2, 7, 18, 19, 22, 25, 28, 29, 32):
+        c = _field(n) if n != 7 else None
+        if c is None:
+            keep = list(case['grid_probs'])[:7]
+            c = dict(case, **{k: {d: (v[:7] if k == 'grid_probs' else v) for d, v in case[k].items() if d in keep}
+                              for k in ('grid_probs', 'base_pace', 'tire_deg', 'driver_variance', 'driver_dnf_rates')})
+        ref = O.Problem(c).run(1500, rng=O.RNG_PHILOX53, seed=7, want_orders=True)
+        sim = RaceSimulator(RaceConfig(**c['config']), set_pop=O.load_cases()['set_pop'], deviates=53)
+        _, orders = sim.run_monte_carlo(1500, c['grid_probs'], c['base_pace'], c['tire_deg'], c['driver_variance'],
+                                        c['driver_dnf_rates'], seed=7, track_condition=c['track_condition'], return_orders=True)
+        assert N.lib().mcgp_last_kernel_name(0).decode() == f'mcgp::race_kernel_reg_wide<{n}>'
+        assert np.array_equal(orders, ref['orders']) and np.array_equal(sim.last_histogram, ref['hist']), n
+    slow = copy.deepcopy(case)
+    slow['config']['overtake_delta'] = -0.5
+    sim = RaceSimulator(RaceConfig(**slow['config']), deviates=53)
     with pytest.raises(N.McgpError) as e:
-        sim.run_monte_carlo(100, sub['grid_probs'], sub['base_pace'], sub['tire_deg'], sub['driver_variance'],
-                            sub['driver_dnf_rates'], seed=1)
-    assert e.value.code == -1 and '10, 20 and 21' in str(e.value)
+        sim.run_monte_carlo(100, slow['grid_probs'], slow['base_pace'], slow['tire_deg'], slow['driver_variance'],
+                            slow['driver_dnf_rates'], seed=1)
+    assert e.value.code == -1 and 'reg_kernel_serves' in str(e.value)
     with pytest.raises(ValueError):
         RaceSimulator(RaceConfig(**case['config']), deviates=64).run_monte_carlo(
             10, case['grid_probs'], case['base_pace'], case['tire_deg'], case['driver_variance'])

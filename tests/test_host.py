@@ -1,7 +1,9 @@
 """Host-side logic and the C-ABI surface; no GPU needed (no compute entry point is called
 successfully here: without a device they must fail loudly)."""
 import ctypes as C
+import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -147,6 +149,31 @@ def test_one_hip_runtime_whichever_is_loaded_first():
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.split() == ['2', '0'], out.stdout          # the failure mode, detected
+
+
+def test_every_hashed_source_is_a_make_prerequisite():
+    """an object that does not depend on a header the identity hash covers would stay stale under a fresh
+    hash.  Every file csrc/source_hash.py hashes must be a prerequisite of the object(s) it is compiled into: every
+    header of every object, mcgp_hip.hip / source_hash.py of the object that carries the hash."""
+    import subprocess
+    csrc = os.path.join(O.ROOT, 'monte_carlo_gp_amd', 'csrc')
+    sys.path.insert(0, csrc)
+    try:
+        import source_hash
+        hashed = {os.path.basename(f) for f in source_hash.sources()}
+    finally:
+        sys.path.remove(csrc)
+    db = subprocess.run(['make', '-pn', '-C', csrc, 'build/reg_inst_20.o', 'build/mcgp_hip.o'], capture_output=True,
+                        text=True).stdout
+    deps = {}
+    for line in db.splitlines():
+        for target in ('build/reg_inst_20.o', 'build/mcgp_hip.o'):
+            if line.startswith(target + ':'):
+                deps[target] = {os.path.basename(x) for x in line.split(':', 1)[1].split()}
+    headers = {f for f in hashed if f.endswith('.h')}
+    assert headers and 'sort_networks.h' in headers and 'normal53_table.h' in headers
+    assert headers | {'reg_inst.hip', 'Makefile'} <= deps['build/reg_inst_20.o'], headers - deps['build/reg_inst_20.o']
+    assert hashed <= deps['build/mcgp_hip.o'], hashed - deps['build/mcgp_hip.o']
 
 
 def test_a_stale_library_is_refused(tmp_path):

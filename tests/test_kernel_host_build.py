@@ -88,10 +88,9 @@ def test_inverse_normal_transform_matches_the_oracle_word_for_word():
         assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), hex(w)
 
 
-@pytest.mark.parametrize('n', [1, 2, 5, 9, 13, 17, 18, 22, 25, 26, 28, 32])
-def test_field_sizes_up_to_the_abi_maximum(n):
-    """Every register instantiation is the same source; sizes beyond the golden / fuzz cases, with an all-zero
-    grid column (uniform fallback, reference :126-129) and per-driver spreads."""
+def _field_of(n):
+    """An n-car field with S60's parameters, 30 laps, an all-zero grid column (uniform fallback, reference :126-129) and
+    per-driver spreads."""
     rng = np.random.default_rng(n)
     drivers = [f'D{i:02d}' for i in range(n)]
     base = O.load_case('S60')
@@ -105,6 +104,14 @@ def test_field_sizes_up_to_the_abi_maximum(n):
     case['tire_deg'] = {d: 0.03 + 0.002 * i for i, d in enumerate(drivers)}
     case['driver_variance'] = {d: 0.2 for d in drivers}
     case['driver_dnf_rates'] = {d: 0.01 for d in drivers}
+    return case
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 9, 13, 17, 18, 22, 25, 26, 28, 32])
+def test_field_sizes_up_to_the_abi_maximum(n):
+    """Every register instantiation is the same source; sizes beyond the golden / fuzz cases, with an all-zero
+    grid column (uniform fallback, reference :126-129) and per-driver spreads."""
+    case = _field_of(n)
     ref = O.Problem(case).run(300, rng=O.RNG_PHILOX, seed=5, want_orders=True)
     hist, orders = K.run(case, 300, 5)
     assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
@@ -164,19 +171,64 @@ def test_register_kernel_domain():
 
 
 def test_fuzzed_configurations_at_reference_width():
-    """The host build of reg_simulate<N, true> against the oracle's PHILOX53 back-end on the fuzz configurations of 10, 20
-    and 21 cars (the GPU run of the same comparison: tests/test_gpu_fuzz.py)."""
+    """The host build of reg_simulate<N, true> against the oracle's PHILOX53 back-end on every fuzz configuration the
+    register kernel takes, whatever its field size (the GPU run of the same comparison: tests/test_gpu_fuzz.py)."""
     with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
         cases = json.load(f)
-    done = 0
+    done, sizes = 0, set()
     for name, c in cases.items():
-        if len(c['grid_probs']) not in (10, 20, 21) or c['config']['overtake_delta'] < 0:
+        if c['config']['overtake_delta'] < 0:
             continue
-        ref = O.Problem(c).run(200, rng=O.RNG_PHILOX53, seed=c['seed'], want_orders=True)
-        hist, orders = K.run(c, 200, c['seed'], deviates=53)
+        ref = O.Problem(c).run(120, rng=O.RNG_PHILOX53, seed=c['seed'], want_orders=True)
+        try:
+            hist, orders = K.run(c, 120, c['seed'], deviates=53)
+        except K.NotServed:
+            continue
         assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist']), name
         done += 1
-    assert done >= 30
+        sizes.add(len(c['grid_probs']))
+    assert done >= 70 and len(sizes) >= 12, (done, sorted(sizes))
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 18, 19, 22, 23, 28, 29, 32])
+def test_reference_width_at_other_field_sizes(n):
+    """deviates = 53 is built for every field size: 19-22-car sessions, and the sizes where the block's
+    LDS holds all 512 / some / none of the table rows it wants (RegGeo::kNorm53Rows: 28 cars 96 rows, 29+ none)."""
+    case = _field_of(n)
+    ref = O.Problem(case).run(150, rng=O.RNG_PHILOX53, seed=9, want_orders=True)
+    hist, orders = K.run(case, 150, 9, deviates=53)
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+
+
+@pytest.mark.parametrize('name', ['S60', 'EVT', 'HET', 'N10'])
+def test_reference_width_exact_paths_equal_the_fast_paths(name):
+    """The reference-width build decides a Bernoulli draw by the leading word alone unless the word EQUALS the leading
+    word of its threshold (one draw in 2^32), and reads a deviate's table row from LDS unless the block does not hold
+    it (one in 2^32 at 20 cars).  The `wide_exact` host build takes the exact / device-memory path for every draw:
+    same finishing orders as the default host build and as the oracle."""
+    case = O.load_case(name)
+    ref = O.Problem(case).run(300, rng=O.RNG_PHILOX53, seed=42, want_orders=True)
+    hist, orders = K.run(case, 300, 42, deviates=53, variant='wide_exact')
+    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+    hist2, orders2 = K.run(case, 300, 42, deviates=53)
+    assert np.array_equal(orders2, orders) and np.array_equal(hist2, hist)
+    # ... and a build in which a few per cent of the draws count as ties (a word within 2^27 of its threshold's leading
+    # word): the exact path entered by simulations that need it and by their neighbours that do not
+    hist3, orders3 = K.run(case, 300, 42, deviates=53, variant='wide_near_ties')
+    assert np.array_equal(orders3, orders) and np.array_equal(hist3, hist)
+
+
+def test_reference_width_threshold_ties_take_the_exact_path():
+    """Probabilities chosen so that draw words DO equal the leading word of their threshold: an event probability of 1
+    (T = 2^53: every word is below), of 0 (T = 0: a word of 0 ties) and pace gaps beyond the 0.5 cap (thr = 2^31)."""
+    import copy
+    case = copy.deepcopy(O.load_case('EVT'))
+    for key, val in (('sc_probability', 1.0), ('vsc_probability', 0.0), ('red_flag_probability', 2.0 ** -40)):
+        c = copy.deepcopy(case)
+        c['config'][key] = val
+        ref = O.Problem(c).run(200, rng=O.RNG_PHILOX53, seed=3, want_orders=True)
+        hist, orders = K.run(c, 200, 3, deviates=53)
+        assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist']), key
 
 
 def test_thousand_lap_race():

@@ -77,22 +77,20 @@ static int run_size(const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offse
                     uint8_t *orders, const uint8_t *fixed_grid)
 {
     if constexpr (N % EMU_PARTS == EMU_PART) {
-        // the reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53) exists for the sizes the library builds it for
+        // the reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53), in its own geometry (WideGeo: blocks of 8 waves,
+        // rows of the binary64 inverse-normal table in LDS)
         if (kp.wide) {
-            if constexpr (N == 10 || N == 20 || N == 21) {
-                constexpr uint32_t B = mcgp::RegGeo<N>::B;
-                const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
-                for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N>(&kp, mcgp::smem, t);
-                std::vector<uint32_t> retire_ws((size_t)(N + 1) * B);
-                for (uint32_t t = 0; t < B; ++t)
-                    mcgp::reg_simulate<N, true>(&kp, mcgp::smem, t, nullptr, n_sims, sim_offset, (uint32_t)seed,
-                                                (uint32_t)(seed >> 32), orders, fixed_grid, n_chunks, retire_ws.data(), B, 0u,
-                                                reinterpret_cast<const double *>(mcgp_normal53_table_bits));
-                for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N>(mcgp::smem, t, hist);
-                return 0;
-            } else {
-                return -3;
-            }
+            using G = mcgp::WideGeo<N>;
+            constexpr uint32_t B = G::B;
+            const double *tab = reinterpret_cast<const double *>(mcgp_normal53_table_bits);
+            const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
+            for (uint32_t t = 0; t < B; ++t) mcgp::reg_load_tables<N, G>(&kp, mcgp::smem, t, tab);
+            std::vector<uint32_t> retire_ws((size_t)(N + 1) * B);
+            for (uint32_t t = 0; t < B; ++t)
+                mcgp::reg_simulate<N, true, G>(&kp, mcgp::smem, t, nullptr, n_sims, sim_offset, (uint32_t)seed,
+                                               (uint32_t)(seed >> 32), orders, fixed_grid, n_chunks, retire_ws.data(), B, 0u, tab);
+            for (uint32_t t = 0; t < B; ++t) mcgp::reg_flush_hist<N, G>(mcgp::smem, t, hist);
+            return 0;
         }
         // one block at a time; inside a block the three phases of the kernel run for every "thread" in turn
         constexpr uint32_t B = mcgp::RegGeo<N>::B;

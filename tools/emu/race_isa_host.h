@@ -97,12 +97,12 @@ inline uint32_t first_lane_with(bool pred) { return pred ? 0u : 64u; }
 inline void sched_fence() {}
 inline double ceil_f64(double x) { return std::ceil(x); }
 inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-template <uint32_t STRIDE>
+template <uint32_t STRIDE, bool CEIL = true>
 inline void ovt_threshold(double dl, double od, uint32_t row, uint32_t &thr, uint32_t &next)
 {
     const uint32_t stride = STRIDE;
     const bool c = dl > od;
-    thr = c ? min_u32(cvt_u32_f64_sat(std::ceil(dl)), 0x80000000u) : 0u;
+    thr = c ? min_u32(cvt_u32_f64_sat(CEIL ? std::ceil(dl) : dl), 0x80000000u) : 0u;
     next = row + (c ? stride : 0u);
 }
 // threads of the emulated block run one after another: "any lane" is this thread alone (both paths behind an
