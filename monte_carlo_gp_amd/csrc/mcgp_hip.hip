@@ -362,7 +362,8 @@ KernelFn select_kernel(const mcgp::KParams &kp, bool *is_reg)
 // block size and LDS footprint are compile-time functions of the field size (RegGeo<N>, shared with the
 // kernel); the number of blocks per CU follows from LDS and the kernel's register allocation.
 void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kernel, uint64_t n_sims, uint32_t *grid,
-                     uint32_t *block, uint32_t *lds, int reg_waves = 0 /* 0: the register kernel's default block shape */)
+                     uint32_t *block, uint32_t *lds, int reg_waves = 0 /* 0: the register kernel's default block shape */,
+                     int total_laps = 0)
 {
     // waves per CU the kernel's register allocation admits: 4 SIMDs x floor(512 / VGPRs, granule 8), at most 8 each
     int reg_cap = 8;
@@ -381,7 +382,7 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kerne
     if (is_reg) {
         // (reg_waves != 0: the reference-width build, whose block also holds rows of the binary64 inverse-normal table)
         waves = reg_waves ? reg_waves : mcgp::reg_block_waves((int)n);
-        bytes = reg_waves ? mcgp::wide_lds_bytes((int)n, reg_waves)
+        bytes = reg_waves ? mcgp::wide_launch_lds_bytes((int)n, reg_waves, total_laps)
                           : mcgp::shared_lds_bytes_reg((int)n) + (size_t)waves * 64 * mcgp::per_thread_lds_bytes_reg((int)n);
     } else {
         const size_t per_wave = 64 * mcgp::per_thread_lds_bytes((int)n);
@@ -526,7 +527,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     for (uint64_t done = 0; done < n_sims; done += cap) {
         const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
         launch_geometry(c, (uint32_t)kp.n, is_reg, wide ? reinterpret_cast<KernelFn>(wide) : kernel, m, &grid, &block, &lds,
-                        wide ? mcgp::wide_block_waves(kp.n) : 0);
+                        wide ? mcgp::wide_block_waves(kp.n) : 0, kp.total_laps);
         // units of work: the register kernel's waves claim chunks of 64 simulations from the stream's counter, a block
         // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
         const uint64_t unit = is_reg ? 64u : block;

@@ -155,7 +155,13 @@ __host__ __device__ constexpr size_t reg_retire_ws_bytes(int n, size_t lanes) { 
 
 // (WAVES: the default is the block shape measured best for the field size; the reference-width build runs at 2 waves per
 //  SIMD -- 256 registers instead of 168, which its binary64 deviates want -- in blocks of 8 waves)
-constexpr int kWideBlockWaves = 8;
+#ifndef MCGP_WIDE_BLOCK_WAVES
+#define MCGP_WIDE_BLOCK_WAVES 8
+#endif
+#ifndef MCGP_WIDE_MIN_WAVES
+#define MCGP_WIDE_MIN_WAVES 2          // waves per SIMD the reference-width build is compiled for (register budget 512 / this)
+#endif
+constexpr int kWideBlockWaves = MCGP_WIDE_BLOCK_WAVES;
 // The reference-width build keeps the binary64 inverse-normal table (normal53_table.h: 784 rows of 8 coefficients, 64 B
 // each) in LDS, behind the per-lane planes, instead of the 7 KB binary32 table it has no use for: as many of the table's
 // LAST rows -- the cells of the largest tail indices -- as fit beside the block's other data, in whole octaves of 16 rows,
@@ -177,6 +183,18 @@ __host__ __device__ constexpr int wide_lds_rows(int n, int waves)
 __host__ __device__ constexpr size_t wide_lds_bytes(int n, int waves)
 {
     return wide_fixed_lds_bytes(n, waves) + (size_t)wide_lds_rows(n, waves) * kNormal53RowBytes;
+}
+// ... and, behind the table rows, the 64-bit survival thresholds of the retirement draw (S_k per lap and driver, the same
+// for every race of the launch: reg_load_tables) when the race is short enough for them to fit -- a 20-car block has room
+// for about 150 laps; longer races work the chain out per wave on the scalar unit, as the default build does in 32 bits.
+__host__ __device__ constexpr size_t wide_chain_bytes(int n, int total_laps)
+{
+    return total_laps >= 2 ? (size_t)(total_laps - 1) * (size_t)((n + 3) & ~3) * 8 : 0;
+}
+__host__ __device__ constexpr size_t wide_launch_lds_bytes(int n, int waves, int total_laps)
+{
+    const size_t base = wide_lds_bytes(n, waves), chain = wide_chain_bytes(n, total_laps);
+    return base + chain + kLdsReserve <= kLdsPerCu ? base + chain : base;
 }
 template <int N, int WAVES = reg_block_waves(N), bool WIDE = false>
 struct RegGeo {
@@ -204,6 +222,13 @@ struct RegGeo {
     static constexpr int kNorm53Rows = WIDE ? wide_lds_rows(N, WAVES) : 0;
     static constexpr int kNorm53First = kNormal53Rows - kNorm53Rows;
     static constexpr uint32_t kBytes = oNorm53 + (uint32_t)kNorm53Rows * (uint32_t)kNormal53RowBytes;
+    // WIDE: [lap - 2][driver, padded to a multiple of 4] u64 survival thresholds of the retirement draw, if they fit
+    static constexpr uint32_t oChain = kBytes;
+    static constexpr uint32_t kChainStride = (uint32_t)((N + 3) & ~3) * 8u;
+    __host__ __device__ static constexpr bool chain_fits(int total_laps)
+    {
+        return WIDE && total_laps >= 2 && kBytes + wide_chain_bytes(N, total_laps) + kLdsReserve <= kLdsPerCu;
+    }
     static_assert(oW == shared_lds_bytes_reg(N) - (WIDE ? (size_t)kNormalRows * 16 : 0) && oLast % 8 == 0, "LDS map");
     static_assert(oW % 16 == 0 && oNorm53 % 16 == 0, "the event handler parks fields with 16-byte LDS accesses (ds_write_b128 / ds_read_b128); table rows are read 16 bytes at a time");
     static_assert(kBytes == (WIDE ? wide_lds_bytes(N, WAVES) : per_thread_lds_bytes_reg(N) * B + shared_lds_bytes_reg(N)), "LDS map");
@@ -515,6 +540,12 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #ifndef MCGP_DISTINCT_PATH
 #define MCGP_DISTINCT_PATH 1       // update_positions_reg<N, true> for the wave-laps whose fields have no equal times
 #endif
+#ifndef MCGP_WIDE_STEP_BATCH
+#define MCGP_WIDE_STEP_BATCH 4
+#endif
+#ifndef MCGP_WIDE_PACE_BATCH
+#define MCGP_WIDE_PACE_BATCH 5
+#endif
 #ifndef MCGP_PACE_BATCH
 #define MCGP_PACE_BATCH 5          // slots whose pace gathers are in flight together in an overtake pass (10: same speed, 52 B of spills against 20)
 #endif
@@ -583,6 +614,18 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
         // the rows of the binary64 inverse-normal table this block keeps in LDS (RegGeo: the table's last kNorm53Rows)
         double *t53 = reinterpret_cast<double *>(smem + G::oNorm53);
         for (uint32_t i = tid; i < (uint32_t)G::kNorm53Rows * 8u; i += B) t53[i] = norm53[(uint32_t)G::kNorm53First * 8u + i];
+        // the retirement chain of every driver (reference :190-197 drawn once per race, 64-bit form: S_2 = q,
+        // S_{k+1} = floor(S_k q / 2^64), q = 2^64 - ceil(p 2^64)), one thread per driver; padding drivers get zeros
+        if (G::chain_fits(P->total_laps)) {
+            for (uint32_t d = tid; d < G::kChainStride / 8u; d += B) {
+                const uint64_t q = d < (uint32_t)N ? P->q64_dnf[d] : 0ull;
+                uint64_t S = q;
+                for (int k = 2; k <= P->total_laps; ++k) {
+                    *reinterpret_cast<uint64_t *>(smem + G::oChain + (uint32_t)(k - 2) * G::kChainStride + d * 8u) = S;
+                    S = __umul64hi(S, q);
+                }
+            }
+        }
     } else {
         float4 *t_norm = reinterpret_cast<float4 *>(smem + G::oNorm);
         for (uint32_t i = tid; i < (uint32_t)kNormalRows * 4; i += B)
@@ -663,7 +706,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                              uint32_t ws_first_lane, const double *__restrict__ norm53 = nullptr)
 {
     constexpr int B = G::B;
-    static_assert(MCGP_STEP_BATCH % 4 == 0, "a Philox block serves four consecutive places");
+    // slots in flight together in the lap step / in an overtake pass (the reference-width build has 256 registers to spend)
+    constexpr int kStepBatch = WIDE ? MCGP_WIDE_STEP_BATCH : MCGP_STEP_BATCH;
+    constexpr int kPaceBatch = WIDE ? MCGP_WIDE_PACE_BATCH : MCGP_PACE_BATCH;
+    static_assert(kStepBatch % 4 == 0, "a Philox block serves four consecutive places");
     const uint32_t tid4 = tid * 4u, tid8 = tid * 8u;
     const int L = P->total_laps;
     const int track = P->track;
@@ -1010,6 +1056,16 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         S64[j] = q64[j];
                         survived[j] = 0u;
                     }
+                    if (G::chain_fits(L)) {
+                        // the thresholds of these four drivers, lap by lap, from the block's table (wave-uniform reads)
+                        uint32_t a = G::oChain + (uint32_t)d0 * 8u;
+#pragma unroll 1
+                        for (int k = 2; k <= L; ++k) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) survived[j] += Q[j] < lds_ld<uint64_t>(a + 8u * j) ? 1u : 0u;
+                            a += G::kChainStride;
+                        }
+                    } else {
 #pragma unroll 1
                     for (int k = 2; k <= L; ++k) {
 #pragma unroll
@@ -1017,6 +1073,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                             survived[j] += Q[j] < S64[j] ? 1u : 0u;
                             S64[j] = __umul64hi(S64[j], q64[j]);
                         }
+                    }
                     }
                 } else {
                 uint32_t q[4], S[4];
@@ -1327,7 +1384,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 
             // ---- every running car's lap (:179-223) with its pit stop (:433-494), in time-rank order ----
             // Written without branches: every slot computes its lap and the results are merged by selects, so the
-            // LDS gathers of MCGP_STEP_BATCH slots stay in flight together (nothing can be sunk into a branch) and
+            // LDS gathers of kStepBatch slots stay in flight together (nothing can be sunk into a branch) and
             // the wave does not pay exec-mask bookkeeping per car.  What a retired car "computes" is discarded:
             // +0.0 on its time, its pk kept, and a LAST value nobody reads (only running cars feed `carry`).
             // The lap-noise draws of places 4j .. 4j+3 are the four words of ONE Philox block, computed here between the
@@ -1343,15 +1400,15 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 if constexpr (reg_min_waves(N) <= 3) pin(retire_word);      // (at 4+ waves per SIMD the register it takes is spilled)
                 double carry = 0.0;
 #pragma unroll
-                for (int i0 = 0; i0 < ((MCGP_SKIP & 64) ? 0 : N); i0 += MCGP_STEP_BATCH) {
+                for (int i0 = 0; i0 < ((MCGP_SKIP & 64) ? 0 : N); i0 += kStepBatch) {
                     MCGP_SCHED_FENCE();          // one batch at a time: gathers hoisted from later batches cost registers
-                    SlotIn in[MCGP_STEP_BATCH];
+                    SlotIn in[kStepBatch];
 #pragma unroll
-                    for (int j = 0; j < MCGP_STEP_BATCH; ++j)
+                    for (int j = 0; j < kStepBatch; ++j)
                         if (i0 + j < N) in[j] = load_slot(pk[i0 + j], lut_base);
-                    uint32_t w[MCGP_STEP_BATCH / 4][4], x[MCGP_STEP_BATCH / 4][4];
+                    uint32_t w[kStepBatch / 4][4], x[kStepBatch / 4][4];
 #pragma unroll
-                    for (int b = 0; b < MCGP_STEP_BATCH / 4; ++b) {
+                    for (int b = 0; b < kStepBatch / 4; ++b) {
                         w[b][0] = w[b][1] = w[b][2] = w[b][3] = 0u;
                         x[b][0] = x[b][1] = x[b][2] = x[b][3] = 0u;
                         if (i0 + 4 * b < N) {
@@ -1364,22 +1421,22 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     }
                     // the lap-noise deviate: binary32 from the cubic table, or (WIDE) binary64 from the degree-7 table
                     using Deviate = std::conditional_t<WIDE, double, float>;
-                    Deviate z[MCGP_STEP_BATCH];
+                    Deviate z[kStepBatch];
                     if constexpr (WIDE) {
                         // rows named for the whole batch, then fetched (4 x ds_read_b128 each), then evaluated; a batch with
                         // a deviate whose row is not in LDS (kRareHi) reads all its rows from device memory instead
-                        uint32_t zhi[MCGP_STEP_BATCH];
-                        double zt[MCGP_STEP_BATCH];
+                        uint32_t zhi[kStepBatch];
+                        double zt[kStepBatch];
                         bool rare = G::kNorm53Rows == 0 || MCGP_WIDE_EXACT;
 #pragma unroll
-                        for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
+                        for (int j = 0; j < kStepBatch; ++j) {
                             normal53_prepare(w[j >> 2][j & 3], x[j >> 2][j & 3], zhi[j], zt[j]);
                             rare |= (i0 + j < N) && zhi[j] < kRareHi;
                         }
                         MCGP_STAT(15, rare);
                         if (__builtin_expect(!MCGP_ANY(rare), 1)) {
 #pragma unroll
-                            for (int j0 = 0; j0 < MCGP_STEP_BATCH; j0 += 2) {
+                            for (int j0 = 0; j0 < kStepBatch; j0 += 2) {
                                 double zc[2][8];
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) norm53_row(zhi[j0 + j], zc[j]);
@@ -1389,14 +1446,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                             }
                         } else {
 #pragma unroll
-                            for (int j = 0; j < MCGP_STEP_BATCH; ++j)
+                            for (int j = 0; j < kStepBatch; ++j)
                                 z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
                         }
                     } else {
                         // two table rows are fetched at a time, then evaluated (half the LDS round trips in a row; four at a
                         // time cost sixteen registers the loop does not have)
 #pragma unroll
-                        for (int j0 = 0; j0 < MCGP_STEP_BATCH; j0 += 2) {
+                        for (int j0 = 0; j0 < kStepBatch; j0 += 2) {
                             uint32_t zrow[2];
                             float zt[2];
                             float4 zc[2];
@@ -1410,7 +1467,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < MCGP_STEP_BATCH; ++j) {
+                    for (int j = 0; j < kStepBatch; ++j) {
                         const int i = i0 + j;
                         if (i >= N) continue;
                         const SlotIn &s = in[j];
@@ -1569,7 +1626,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                     // the pair a candidate
                     uint32_t row = tid4;
                     {
-                        constexpr int H = MCGP_PACE_BATCH;
+                        constexpr int H = kPaceBatch;
                             double pace_prev = 0.0;
 #pragma unroll
                         for (int h = 0; h < N; h += H) {
@@ -1767,7 +1824,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
 
 // The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): same phases, blocks of 8 waves at 2 waves per SIMD.
 template <int N>
-__global__ void __launch_bounds__((WideGeo<N>::B), 2)
+__global__ void __launch_bounds__((WideGeo<N>::B), MCGP_WIDE_MIN_WAVES)
 race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                      uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                      uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,

@@ -240,3 +240,10 @@ def test_thousand_lap_race():
     ref = O.Problem(case).run(24, rng=O.RNG_PHILOX, seed=3, want_orders=True)
     hist, orders = K.run(case, 24, 3)
     assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist'])
+    # ... and at reference width, where the block's LDS has no room for a 1000-lap table of retirement thresholds (the
+    # chain is then worked out per wave) -- and a 400-lap race, whose table still fits a 10-car block
+    for laps, n_sims in ((1000, 16), (400, 24)):
+        case['config']['total_laps'] = laps
+        ref = O.Problem(case).run(n_sims, rng=O.RNG_PHILOX53, seed=3, want_orders=True)
+        hist, orders = K.run(case, n_sims, 3, deviates=53)
+        assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist']), laps
