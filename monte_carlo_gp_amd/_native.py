@@ -45,22 +45,45 @@ class McgpDrivers(C.Structure):
                 ('base_pace', 'tire_deg', 'tire_deg_pit', 'variance', 'team_dnf', 'lap_dnf')]
 
 
+_hash_module = None
+_hash_cache = {}            # key -> value; keys carry (path, mtime_ns, size) of every file the value was read from
+
+
 def _load_source_hash_module():
-    import importlib.util
-    spec = importlib.util.spec_from_file_location('_mcgp_source_hash', os.path.join(CSRC, 'source_hash.py'))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
+    global _hash_module
+    if _hash_module is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('_mcgp_source_hash', os.path.join(CSRC, 'source_hash.py'))
+        _hash_module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_hash_module)
+    return _hash_module
 
 
 def _sources():
     return _load_source_hash_module().sources()
 
 
+def _stat_key(paths):
+    key = []
+    for path in sorted(paths):
+        try:
+            st = os.stat(path)
+            key.append((path, st.st_mtime_ns, st.st_size))
+        except OSError:
+            key.append((path, None, None))
+    return tuple(key)
+
+
 def source_hash():
     """Identity of the kernel sources in this tree (csrc/source_hash.py): the Makefile compiles the same value into
-    libmcgp_hip.so, and profiles under profiles/ are stamped with it."""
-    return _load_source_hash_module().source_hash()
+    libmcgp_hip.so, and profiles under profiles/ are stamped with it.  Cached per process on (path, mtime, size) of
+    every hashed file: every rank of a launch asks several times at start-up."""
+    key = ('src',) + _stat_key(_sources())
+    if key not in _hash_cache:
+        for k in [k for k in _hash_cache if k[0] == 'src']:
+            del _hash_cache[k]
+        _hash_cache[key] = _load_source_hash_module().source_hash()
+    return _hash_cache[key]
 
 
 _MARKER = b'MCGP_BUILD_HASH='
@@ -68,17 +91,36 @@ _MARKER = b'MCGP_BUILD_HASH='
 
 def file_build_hash(path):
     """The source hash a library FILE was compiled from, read from its marker string without loading it
-    (None: no such file, or a binary without the marker)."""
+    (None: no such file, or a binary without the marker).  The file (tens of megabytes of kernels) is scanned in
+    pieces, not read whole, and the answer is cached per process on (path, mtime, size)."""
+    key = ('lib',) + _stat_key([path])
+    if key in _hash_cache:
+        return _hash_cache[key]
+    found = None
     try:
         with open(path, 'rb') as f:
-            blob = f.read()
+            tail = b''
+            while found is None:
+                piece = f.read(1 << 20)
+                if not piece:
+                    break
+                blob = tail + piece
+                i = blob.find(_MARKER)
+                if i >= 0:
+                    rest = blob[i + len(_MARKER):]
+                    while b'\0' not in rest:                    # the value straddles the end of this piece
+                        more = f.read(4096)
+                        if not more:
+                            break
+                        rest += more
+                    found = rest.split(b'\0', 1)[0].decode('ascii', 'replace')
+                tail = blob[-(len(_MARKER) - 1):]
     except OSError:
         return None
-    i = blob.find(_MARKER)
-    if i < 0:
-        return None
-    j = blob.find(b'\0', i)
-    return blob[i + len(_MARKER):j].decode('ascii', 'replace')
+    for k in [k for k in _hash_cache if k[0] == 'lib' and k[1][0] == path]:
+        del _hash_cache[k]
+    _hash_cache[key] = found
+    return found
 
 
 def _stale():

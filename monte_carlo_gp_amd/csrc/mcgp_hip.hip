@@ -119,6 +119,7 @@ elo_season_kernel(int n, int n_events, const int32_t *__restrict__ kind, const d
 constexpr int kParamSlots = 4;
 constexpr int kSlotReaders = 8;        // streams with a launch in flight on one parameter block
 constexpr int kStreamTimers = 8;       // streams whose most recent call keeps its own timing events
+constexpr int kBatchTimer = -2;        // DeviceCtx::last_timer after mcgp_run_batch: the call's own pair of events
 
 struct DeviceCtx {
     std::mutex mu;
@@ -173,6 +174,7 @@ struct DeviceCtx {
     size_t batch_bytes = 0;
     uint32_t *d_batch_retire = nullptr;     // ... and the lanes' retirement lists
     size_t batch_retire_bytes = 0;
+    hipEvent_t batch_start = nullptr, batch_stop = nullptr;     // ... and the timing events of the last batch call
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     char last_kernel[48] = "";
 };
@@ -224,6 +226,9 @@ void release_ctx(DeviceCtx &c)
     c.elo_bytes = 0;
     if (c.d_batch) (void)hipFree(c.d_batch);
     if (c.d_batch_retire) (void)hipFree(c.d_batch_retire);
+    if (c.batch_start) (void)hipEventDestroy(c.batch_start);
+    if (c.batch_stop) (void)hipEventDestroy(c.batch_stop);
+    c.batch_start = c.batch_stop = nullptr;
     c.d_batch = nullptr;
     c.d_batch_retire = nullptr;
     c.batch_bytes = c.batch_retire_bytes = 0;
@@ -247,6 +252,10 @@ int init_ctx_body(int device, DeviceCtx &c)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c.cu_count = prop.multiProcessorCount;
     c.lds_per_block = prop.sharedMemPerBlock;       // 160 KiB on gfx950
+    if (const char *e = std::getenv("MCGP_LDS_PER_BLOCK")) {      // tests: a device / runtime that offers less LDS per block
+        const unsigned long long v = std::strtoull(e, nullptr, 10);
+        if (v >= 16384 && v < c.lds_per_block) c.lds_per_block = (size_t)v;
+    }
     for (auto &sl : c.slot) {
         HIP_TRY(hipMalloc(&sl.dev, sizeof(mcgp::KParams)));
         HIP_TRY(hipHostMalloc(&sl.host, sizeof(mcgp::KParams)));
@@ -262,11 +271,7 @@ int init_ctx_body(int device, DeviceCtx &c)
     HIP_TRY(hipMemcpy(c.d_norm53, mcgp_normal53_table_bits, sizeof(mcgp_normal53_table_bits), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
-#define X(N_)                                                                                         \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcgp::race_kernel_reg<N_>),           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_per_block));
-    MCGP_REG_SIZES(X)
-#undef X
+    // (the register kernels raise their dynamic-LDS limit when they are selected: launch())
     return MCGP_OK;
 }
 
@@ -306,6 +311,11 @@ namespace mcgp {
                                                                   uint32_t *, uint32_t *);
 MCGP_REG_SIZES(X)
 #undef X
+#define X(N_) extern template __global__ void race_kernel_reg<N_, kSmallBlockWaves>(const KParams *, uint64_t, uint64_t, uint32_t, \
+                                                                                    uint32_t, unsigned long long *, uint8_t *,   \
+                                                                                    const uint8_t *, uint32_t, uint32_t *, uint32_t *);
+MCGP_REG_SIZES(X)
+#undef X
 #define X(N_) extern template __global__ void race_kernel_reg_wide<N_>(const KParams *, uint64_t, uint64_t, uint32_t, uint32_t, \
                                                                        unsigned long long *, uint8_t *, const uint8_t *, uint32_t, \
                                                                        uint32_t *, uint32_t *, const double *);
@@ -343,6 +353,17 @@ BatchKernelFn select_batch_kernel(uint32_t n)
     }
 }
 
+// the register kernel of a field size in its small block shape (kSmallBlockWaves)
+KernelFn select_small_kernel(uint32_t n)
+{
+    switch (n) {
+#define X(N_) case N_: return &mcgp::race_kernel_reg<N_, mcgp::kSmallBlockWaves>;
+        MCGP_REG_SIZES(X)
+#undef X
+        default: return nullptr;
+    }
+}
+
 KernelFn select_kernel(const mcgp::KParams &kp, bool *is_reg)
 {
     *is_reg = false;
@@ -363,7 +384,7 @@ KernelFn select_kernel(const mcgp::KParams &kp, bool *is_reg)
 // kernel); the number of blocks per CU follows from LDS and the kernel's register allocation.
 void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kernel, uint64_t n_sims, uint32_t *grid,
                      uint32_t *block, uint32_t *lds, int reg_waves = 0 /* 0: the register kernel's default block shape */,
-                     int total_laps = 0)
+                     bool wide = false /* the reference-width build: its block also holds table rows (WideGeo) */, int total_laps = 0)
 {
     // waves per CU the kernel's register allocation admits: 4 SIMDs x floor(512 / VGPRs, granule 8), at most 8 each
     int reg_cap = 8;
@@ -380,10 +401,9 @@ void launch_geometry(const DeviceCtx &c, uint32_t n, bool is_reg, KernelFn kerne
     int waves = 1, blocks_per_cu = 1;
     size_t bytes = 0;
     if (is_reg) {
-        // (reg_waves != 0: the reference-width build, whose block also holds rows of the binary64 inverse-normal table)
         waves = reg_waves ? reg_waves : mcgp::reg_block_waves((int)n);
-        bytes = reg_waves ? mcgp::wide_launch_lds_bytes((int)n, reg_waves, total_laps)
-                          : mcgp::shared_lds_bytes_reg((int)n) + (size_t)waves * 64 * mcgp::per_thread_lds_bytes_reg((int)n);
+        bytes = wide ? mcgp::wide_launch_lds_bytes((int)n, waves, total_laps)
+                     : mcgp::shared_lds_bytes_reg((int)n) + (size_t)waves * 64 * mcgp::per_thread_lds_bytes_reg((int)n);
     } else {
         const size_t per_wave = 64 * mcgp::per_thread_lds_bytes((int)n);
         waves = (int)((c.lds_per_block - mcgp::kSharedTableBytes) / per_wave);
@@ -435,6 +455,46 @@ struct FrontEnd {
     bool on = false;
 };
 
+// The timing events and work counter of `stream` (its most recent call); the least recently used entry is recycled.
+int claim_timer(DeviceCtx &c, hipStream_t stream, int *out)
+{
+    int ti = -1;
+    for (int i = 0; i < kStreamTimers; ++i)
+        if (c.timer[i].used && c.timer[i].stream == stream) { ti = i; break; }
+    if (ti < 0) {
+        ti = 0;
+        for (int i = 0; i < kStreamTimers; ++i) {
+            if (!c.timer[i].used) { ti = i; break; }
+            if (c.timer[i].seq < c.timer[ti].seq) ti = i;
+        }
+        if (!c.timer[ti].d_ticket) {
+            // events and counter are created into locals and committed together: a failure part-way leaves the entry
+            // empty (not an entry with events and a NULL counter for the next launch to hand to the kernel)
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            uint32_t *tk = nullptr;
+            hipError_t err = hipEventCreate(&e0);
+            if (err == hipSuccess) err = hipEventCreate(&e1);
+            if (err == hipSuccess) err = hipMalloc(&tk, sizeof(uint32_t));
+            if (err != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                return fail(err == hipErrorOutOfMemory ? MCGP_E_NOMEM : MCGP_E_HIP,
+                            std::string("stream timer / work counter: ") + hipGetErrorString(err));
+            }
+            c.timer[ti].start = e0;
+            c.timer[ti].stop = e1;
+            c.timer[ti].d_ticket = tk;
+        } else if (c.timer[ti].used) {
+            // recycled from another stream: its last launch may still be claiming work from the entry's counter
+            HIP_TRY(hipEventSynchronize(c.timer[ti].stop));
+        }
+        c.timer[ti].stream = stream;
+        c.timer[ti].used = true;
+    }
+    *out = ti;
+    return MCGP_OK;
+}
+
 int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_offset, uint64_t seed,
            hipStream_t stream, unsigned long long *d_hist, uint8_t *d_orders, const uint8_t *d_fixed_grid,
            const FrontEnd &fe = FrontEnd())
@@ -485,81 +545,93 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
         // cached block uploaded on another stream: order this stream behind that upload
         HIP_TRY(hipStreamWaitEvent(stream, sl->uploaded, 0));
     }
-    // this stream's timing events (its most recent call); the least recently used entry is recycled
     int ti = -1;
-    for (int i = 0; i < kStreamTimers; ++i)
-        if (c.timer[i].used && c.timer[i].stream == stream) { ti = i; break; }
-    if (ti < 0) {
-        ti = 0;
-        for (int i = 0; i < kStreamTimers; ++i) {
-            if (!c.timer[i].used) { ti = i; break; }
-            if (c.timer[i].seq < c.timer[ti].seq) ti = i;
-        }
-        if (!c.timer[ti].d_ticket) {
-            // events and counter are created into locals and committed together: a failure part-way leaves the entry
-            // empty (not an entry with events and a NULL counter for the next launch to hand to the kernel)
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            uint32_t *tk = nullptr;
-            hipError_t err = hipEventCreate(&e0);
-            if (err == hipSuccess) err = hipEventCreate(&e1);
-            if (err == hipSuccess) err = hipMalloc(&tk, sizeof(uint32_t));
-            if (err != hipSuccess) {
-                if (e0) (void)hipEventDestroy(e0);
-                if (e1) (void)hipEventDestroy(e1);
-                return fail(err == hipErrorOutOfMemory ? MCGP_E_NOMEM : MCGP_E_HIP,
-                            std::string("stream timer / work counter: ") + hipGetErrorString(err));
-            }
-            c.timer[ti].start = e0;
-            c.timer[ti].stop = e1;
-            c.timer[ti].d_ticket = tk;
-        } else if (c.timer[ti].used) {
-            // recycled from another stream: its last launch may still be claiming work from the entry's counter
-            HIP_TRY(hipEventSynchronize(c.timer[ti].stop));
-        }
-        c.timer[ti].stream = stream;
-        c.timer[ti].used = true;
+    {
+        const int rc = claim_timer(c, stream, &ti);
+        if (rc != MCGP_OK) return rc;
     }
     c.timer[ti].seq = ++c.timer_seq;
     if (!c.timer[ti].d_ticket) return fail(MCGP_E_HIP, "no work counter for this stream");
     HIP_TRY(hipEventRecord(c.timer[ti].start, stream));
     const uint64_t cap = max_sims_per_launch();
     uint32_t grid = 0, block = 0, lds = 0;
+    // The register kernel's default block fills the CU's LDS to the last half kilobyte at 20 cars (RegGeo).  A device or a
+    // runtime that offers less per block gets the same kernel in blocks of kSmallBlockWaves waves -- less than half the
+    // footprint, about 15 % slower --: chosen up front when the device reports less LDS than the block needs, and once more,
+    // with a fresh launch, when the launch itself is refused for its resources.  The shape in use shows in
+    // mcgp_last_launch_info (block_threads) and mcgp_last_kernel_name.
+    bool small_shape = false;
+    auto resource_error = [](hipError_t e) {
+        return e == hipErrorOutOfMemory || e == hipErrorInvalidValue || e == hipErrorLaunchOutOfResources ||
+               e == hipErrorInvalidConfiguration;
+    };
     for (uint64_t done = 0; done < n_sims; done += cap) {
         const uint64_t m = (n_sims - done) < cap ? (n_sims - done) : cap;
-        launch_geometry(c, (uint32_t)kp.n, is_reg, wide ? reinterpret_cast<KernelFn>(wide) : kernel, m, &grid, &block, &lds,
-                        wide ? mcgp::wide_block_waves(kp.n) : 0, kp.total_laps);
-        // units of work: the register kernel's waves claim chunks of 64 simulations from the stream's counter, a block
-        // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
-        const uint64_t unit = is_reg ? 64u : block;
-        const uint64_t n_batches = (m + unit - 1) / unit;
-        if (is_reg) {
-            HIP_TRY(hipMemsetAsync(c.timer[ti].d_ticket, 0, sizeof(uint32_t), stream));
-            // the lanes' retirement lists: scratch of the launch, (n + 1) words per lane, kept per stream and grown on
-            // demand (a launch of this stream that still uses the old buffer has been enqueued before the free, which
-            // the runtime orders behind it)
-            const size_t want = mcgp::reg_retire_ws_bytes(kp.n, (size_t)grid * block);
-            if (want > c.timer[ti].retire_bytes) {
-                if (c.timer[ti].d_retire) {
-                    HIP_TRY(hipStreamSynchronize(stream));
-                    (void)hipFree(c.timer[ti].d_retire);
-                }
-                c.timer[ti].d_retire = nullptr;
-                c.timer[ti].retire_bytes = 0;
-                HIP_TRY(hipMalloc(&c.timer[ti].d_retire, want));
-                c.timer[ti].retire_bytes = want;
+        for (;;) {
+            KernelFn k = kernel;
+            if (small_shape) {
+                k = select_small_kernel((uint32_t)kp.n);
+                if (!k) return fail(MCGP_E_HIP, "no small-block instantiation for this field size");
             }
+            launch_geometry(c, (uint32_t)kp.n, is_reg, wide ? reinterpret_cast<KernelFn>(wide) : k, m, &grid, &block, &lds,
+                            wide ? mcgp::wide_block_waves(kp.n) : small_shape ? mcgp::kSmallBlockWaves : 0, wide != nullptr,
+                            kp.total_laps);
+            const bool may_shrink = is_reg && !wide && !small_shape;
+            if (may_shrink && lds > c.lds_per_block) {              // the device offers less than the default block needs
+                small_shape = true;
+                continue;
+            }
+            if (lds > c.lds_per_block)
+                return fail(MCGP_E_HIP, "the kernel's smallest block needs " + std::to_string(lds) + " bytes of LDS, the device offers " +
+                                            std::to_string(c.lds_per_block) + " per block");
+            if (is_reg && !wide) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (may_shrink && resource_error(e)) { small_shape = true; continue; }
+                    return fail(MCGP_E_HIP, std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(e));
+                }
+            }
+            // units of work: the register kernel's waves claim chunks of 64 simulations from the stream's counter, a block
+            // of the generic kernel takes batches of `block` by its index (both < 2^32 because m < 2^32)
+            const uint64_t unit = is_reg ? 64u : block;
+            const uint64_t n_batches = (m + unit - 1) / unit;
+            if (is_reg) {
+                HIP_TRY(hipMemsetAsync(c.timer[ti].d_ticket, 0, sizeof(uint32_t), stream));
+                // the lanes' retirement lists: scratch of the launch, (n + 1) words per lane, kept per stream and grown on
+                // demand (a launch of this stream that still uses the old buffer has been enqueued before the free, which
+                // the runtime orders behind it)
+                const size_t want = mcgp::reg_retire_ws_bytes(kp.n, (size_t)grid * block);
+                if (want > c.timer[ti].retire_bytes) {
+                    if (c.timer[ti].d_retire) {
+                        HIP_TRY(hipStreamSynchronize(stream));
+                        (void)hipFree(c.timer[ti].d_retire);
+                    }
+                    c.timer[ti].d_retire = nullptr;
+                    c.timer[ti].retire_bytes = 0;
+                    HIP_TRY(hipMalloc(&c.timer[ti].d_retire, want));
+                    c.timer[ti].retire_bytes = want;
+                }
+            }
+            if (wide)
+                hipLaunchKernelGGL(wide, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
+                                   d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
+                                   (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire, c.d_norm53);
+            else
+                hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
+                                   d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
+                                   (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire);
+            const hipError_t e = hipGetLastError();
+            if (e == hipSuccess) break;
+            if (may_shrink && resource_error(e)) {                  // refused for its resources: once more, small blocks
+                small_shape = true;
+                continue;
+            }
+            return fail(e == hipErrorOutOfMemory ? MCGP_E_NOMEM : MCGP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
         }
-        if (wide)
-            hipLaunchKernelGGL(wide, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
-                               d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
-                               (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire, c.d_norm53);
-        else
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, sl->dev, m, sim_offset + done,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), d_hist,
-                               d_orders ? d_orders + (size_t)done * (size_t)kp.n : nullptr, d_fixed_grid,
-                               (uint32_t)n_batches, c.timer[ti].d_ticket, c.timer[ti].d_retire);
-        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c.timer[ti].stop, stream));
     c.last_timer = ti;
@@ -592,6 +664,7 @@ int launch(DeviceCtx &c, const mcgp::KParams &kp, uint64_t n_sims, uint64_t sim_
     c.last_block = block;
     c.last_lds = lds;
     if (wide) std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel_reg_wide<%d>", kp.n);
+    else if (is_reg && small_shape) std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel_reg<%d, %d>", kp.n, mcgp::kSmallBlockWaves);
     else if (is_reg) std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel_reg<%d>", kp.n);
     else std::snprintf(c.last_kernel, sizeof(c.last_kernel), "mcgp::race_kernel");
     return MCGP_OK;
@@ -905,22 +978,38 @@ int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_
     if (n_problems < 1 || n_problems > 4096) return fail(MCGP_E_BAD_ARG, "n_problems must be in [1, 4096]");
     if (n_sims >= 0xFFFFFE00ull) return fail(MCGP_E_BAD_ARG, "n_sims per problem must be below 2^32 - 512 in a batch");
     if (n_sims == 0) return MCGP_OK;
-    std::vector<mcgp::KParams> kps(n_problems);
-    std::vector<mcgp::BatchItem> items(n_problems);
-    for (uint32_t p = 0; p < n_problems; ++p) {
-        if (!grid_probs[p]) return fail(MCGP_E_BAD_ARG, "a grid_probs pointer of the batch is NULL");
-        const int rc = build_params(&cfgs[p], &drvs[p], grid_probs[p], n, &kps[p]);
-        if (rc != MCGP_OK) return rc;
-        // the batch kernel is the register kernel; a problem only the generic kernel takes (lap times near zero, values
-        // near the ends of binary64) is refused rather than silently run elsewhere: use mcgp_run for it
-        if (kps[p].wide) return fail(MCGP_E_BAD_ARG, "deviates = MCGP_DEVIATES_53 is not available in a batch: use mcgp_run");
-        if (!mcgp::reg_kernel_serves(kps[p]))
-            return fail(MCGP_E_BAD_ARG, "a problem of the batch is outside the register kernel's domain (see reg_kernel_serves): run it with mcgp_run");
-        items[p].sim_offset = sim_offsets ? sim_offsets[p] : 0ull;
-        items[p].seed = seeds[p];
-    }
+    // Every problem gets what mcgp_run would give it (reference src/validation.py:179-185: a sweep is a loop over
+    // independent predictions, none of which can make another one fail).  The problems the batch kernel takes -- the
+    // register kernel's domain at the default deviate width -- share ONE launch; the others (deviates = 53, a problem only
+    // the generic kernel serves, everything under MCGP_FORCE_GENERIC=1) run one after the other through the single-problem
+    // path, inside this call, into the same output.
+    std::vector<mcgp::KParams> kps;                  // the problems of the shared launch, compacted
+    std::vector<mcgp::BatchItem> items;
+    std::vector<uint32_t> shared_index, solo_index;  // original indices
+    std::vector<mcgp::KParams> solo_kps;
+    const char *force = std::getenv("MCGP_FORCE_GENERIC");
+    const bool force_generic = force && force[0] == '1';
     const BatchKernelFn kernel = select_batch_kernel(n);
-    if (!kernel) return fail(MCGP_E_BAD_ARG, "no batch kernel for this field size");
+    {
+        mcgp::KParams kp;
+        for (uint32_t p = 0; p < n_problems; ++p) {
+            if (!grid_probs[p]) return fail(MCGP_E_BAD_ARG, "a grid_probs pointer of the batch is NULL");
+            const int rc = build_params(&cfgs[p], &drvs[p], grid_probs[p], n, &kp);
+            if (rc != MCGP_OK) return rc;
+            if (kp.wide && !mcgp::reg_kernel_serves(kp))
+                return fail(MCGP_E_BAD_ARG, "deviates = MCGP_DEVIATES_53 serves the problems the register kernel takes "
+                                            "(reg_kernel_serves: lap times clear of zero, overtake_delta >= 0)");
+            if (!kernel || force_generic || kp.wide || !mcgp::reg_kernel_serves(kp)) {
+                solo_index.push_back(p);
+                solo_kps.push_back(kp);
+            } else {
+                shared_index.push_back(p);
+                kps.push_back(kp);
+                items.push_back(mcgp::BatchItem{sim_offsets ? sim_offsets[p] : 0ull, seeds[p]});
+            }
+        }
+    }
+    const uint32_t n_shared = (uint32_t)kps.size();
     DeviceCtx *c = nullptr;
     int rc = find_ctx(device, &c);
     if (rc != MCGP_OK) return rc;
@@ -929,72 +1018,92 @@ int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_
         int r = ensure_ctx_locked(device, *c);
         if (r != MCGP_OK) return r;
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)c->lds_per_block));
-        // geometry: the register kernel's block, one more LDS word that names the block's next problem
-        const int waves = mcgp::reg_block_waves((int)n);
-        const uint32_t block = (uint32_t)waves * 64u;
-        const size_t lds = mcgp::shared_lds_bytes_reg((int)n) + (size_t)block * mcgp::per_thread_lds_bytes_reg((int)n) +
-                           mcgp::kBatchLdsExtra;
-        int reg_cap = 4 * mcgp::reg_min_waves((int)n);
-        int blocks_per_cu = (int)(c->lds_per_block / lds);
-        if (blocks_per_cu * waves > reg_cap) blocks_per_cu = reg_cap / waves;
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-        const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
-        // no more blocks than the batch has wave-chunks to fill them with
-        const uint64_t n_tasks = ((uint64_t)n_problems * n_chunks + (uint64_t)waves - 1) / (uint64_t)waves;
-        uint64_t grid = (uint64_t)c->cu_count * (uint64_t)blocks_per_cu;
-        if (grid > n_tasks) grid = n_tasks;
-        // one device buffer: [parameter blocks | items | histograms | one ticket counter per problem]
-        const size_t o_items = sizeof(mcgp::KParams) * n_problems;
-        const size_t o_hist = o_items + sizeof(mcgp::BatchItem) * n_problems;
-        const size_t hist_bytes = sizeof(unsigned long long) * n * n * n_problems;
-        const size_t o_ticket = o_hist + hist_bytes;
-        const size_t ticket_bytes = (sizeof(uint32_t) * n_problems + 15) / 16 * 16;
-        const size_t bytes = o_ticket + ticket_bytes;
-        if (bytes > c->batch_bytes) {
-            if (c->d_batch) (void)hipFree(c->d_batch);
-            c->d_batch = nullptr;
-            c->batch_bytes = 0;
-            HIP_TRY(hipMalloc(&c->d_batch, bytes));
-            c->batch_bytes = bytes;
+        // the call's own pair of timing events (mcgp_last_kernel_ms after a batch call = everything it ran on the device)
+        if (!c->batch_start) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            hipError_t err = hipEventCreate(&e0);
+            if (err == hipSuccess) err = hipEventCreate(&e1);
+            if (err != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                return fail(MCGP_E_HIP, std::string("batch timing events: ") + hipGetErrorString(err));
+            }
+            c->batch_start = e0;
+            c->batch_stop = e1;
         }
-        const size_t ws = mcgp::reg_retire_ws_bytes((int)n, (size_t)grid * block);
-        if (ws > c->batch_retire_bytes) {
-            if (c->d_batch_retire) (void)hipFree(c->d_batch_retire);
-            c->d_batch_retire = nullptr;
-            c->batch_retire_bytes = 0;
-            HIP_TRY(hipMalloc(&c->d_batch_retire, ws));
-            c->batch_retire_bytes = ws;
+        HIP_TRY(hipEventRecord(c->batch_start, nullptr));
+        const size_t cell_bytes = sizeof(unsigned long long) * n * n;
+        if (n_shared) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)c->lds_per_block));
+            // geometry: the register kernel's block, one more LDS word that names the block's next problem
+            const int waves = mcgp::reg_block_waves((int)n);
+            const uint32_t block = (uint32_t)waves * 64u;
+            const size_t lds = mcgp::shared_lds_bytes_reg((int)n) + (size_t)block * mcgp::per_thread_lds_bytes_reg((int)n) +
+                               mcgp::kBatchLdsExtra;
+            int reg_cap = 4 * mcgp::reg_min_waves((int)n);
+            int blocks_per_cu = (int)(c->lds_per_block / lds);
+            if (blocks_per_cu * waves > reg_cap) blocks_per_cu = reg_cap / waves;
+            if (blocks_per_cu < 1) blocks_per_cu = 1;
+            const uint32_t n_chunks = (uint32_t)((n_sims + 63) / 64);
+            // no more blocks than the batch has wave-chunks to fill them with
+            const uint64_t n_tasks = ((uint64_t)n_shared * n_chunks + (uint64_t)waves - 1) / (uint64_t)waves;
+            uint64_t grid = (uint64_t)c->cu_count * (uint64_t)blocks_per_cu;
+            if (grid > n_tasks) grid = n_tasks;
+            // one device buffer: [parameter blocks | items | histograms | one ticket counter per problem]
+            const size_t o_items = sizeof(mcgp::KParams) * n_shared;
+            const size_t o_hist = o_items + sizeof(mcgp::BatchItem) * n_shared;
+            const size_t hist_bytes = cell_bytes * n_shared;
+            const size_t o_ticket = o_hist + hist_bytes;
+            const size_t ticket_bytes = (sizeof(uint32_t) * n_shared + 15) / 16 * 16;
+            const size_t bytes = o_ticket + ticket_bytes;
+            if (bytes > c->batch_bytes) {
+                if (c->d_batch) (void)hipFree(c->d_batch);
+                c->d_batch = nullptr;
+                c->batch_bytes = 0;
+                HIP_TRY(hipMalloc(&c->d_batch, bytes));
+                c->batch_bytes = bytes;
+            }
+            const size_t ws = mcgp::reg_retire_ws_bytes((int)n, (size_t)grid * block);
+            if (ws > c->batch_retire_bytes) {
+                if (c->d_batch_retire) (void)hipFree(c->d_batch_retire);
+                c->d_batch_retire = nullptr;
+                c->batch_retire_bytes = 0;
+                HIP_TRY(hipMalloc(&c->d_batch_retire, ws));
+                c->batch_retire_bytes = ws;
+            }
+            unsigned char *d = c->d_batch;
+            HIP_TRY(hipMemcpyAsync(d, kps.data(), o_items, hipMemcpyHostToDevice, nullptr));
+            HIP_TRY(hipMemcpyAsync(d + o_items, items.data(), sizeof(mcgp::BatchItem) * n_shared, hipMemcpyHostToDevice, nullptr));
+            HIP_TRY(hipMemsetAsync(d + o_hist, 0, hist_bytes + ticket_bytes, nullptr));
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(block), lds, nullptr,
+                               reinterpret_cast<const mcgp::KParams *>(d), reinterpret_cast<const mcgp::BatchItem *>(d + o_items),
+                               n_shared, n_sims, reinterpret_cast<unsigned long long *>(d + o_hist), n_chunks,
+                               reinterpret_cast<uint32_t *>(d + o_ticket), c->d_batch_retire);
+            HIP_TRY(hipGetLastError());
+            std::vector<unsigned long long> h((size_t)n * n * n_shared);
+            HIP_TRY(hipMemcpy(h.data(), d + o_hist, hist_bytes, hipMemcpyDeviceToHost));
+            for (uint32_t j = 0; j < n_shared; ++j) {
+                uint64_t *out = hist_out + (size_t)shared_index[j] * n * n;
+                for (uint32_t i = 0; i < n * n; ++i) out[i] += h[(size_t)j * n * n + i];
+            }
+            c->last_grid = (uint32_t)grid;
+            c->last_block = block;
+            c->last_lds = (uint32_t)lds;
+            std::snprintf(c->last_kernel, sizeof(c->last_kernel), "mcgp::race_kernel_reg_batch<%u>", n);
         }
-        unsigned char *d = c->d_batch;
-        HIP_TRY(hipMemcpyAsync(d, kps.data(), o_items, hipMemcpyHostToDevice, nullptr));
-        HIP_TRY(hipMemcpyAsync(d + o_items, items.data(), sizeof(mcgp::BatchItem) * n_problems, hipMemcpyHostToDevice, nullptr));
-        HIP_TRY(hipMemsetAsync(d + o_hist, 0, hist_bytes + ticket_bytes, nullptr));
-        // timed like the other launches (the default stream's entry)
-        int ti = -1;
-        for (int i = 0; i < kStreamTimers; ++i)
-            if (c->timer[i].used && c->timer[i].stream == nullptr) { ti = i; break; }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ti >= 0) { e0 = c->timer[ti].start; e1 = c->timer[ti].stop; }
-        if (e0) HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(block), lds, nullptr,
-                           reinterpret_cast<const mcgp::KParams *>(d), reinterpret_cast<const mcgp::BatchItem *>(d + o_items),
-                           n_problems, n_sims, reinterpret_cast<unsigned long long *>(d + o_hist), n_chunks,
-                           reinterpret_cast<uint32_t *>(d + o_ticket), c->d_batch_retire);
-        HIP_TRY(hipGetLastError());
-        if (e1) {
-            HIP_TRY(hipEventRecord(e1, nullptr));
-            c->timer[ti].seq = ++c->timer_seq;
-            c->last_timer = ti;
+        // the problems that run by themselves: exactly mcgp_run's path, one after the other (null stream)
+        for (size_t j = 0; j < solo_index.size(); ++j) {
+            const uint32_t p = solo_index[j];
+            HIP_TRY(hipMemsetAsync(c->d_hist, 0, cell_bytes, nullptr));
+            r = launch(*c, solo_kps[j], n_sims, sim_offsets ? sim_offsets[p] : 0ull, seeds[p], nullptr, c->d_hist, nullptr, nullptr);
+            if (r != MCGP_OK) return r;
+            unsigned long long h[MCGP_MAX_CARS * MCGP_MAX_CARS];
+            HIP_TRY(hipMemcpy(h, c->d_hist, cell_bytes, hipMemcpyDeviceToHost));
+            uint64_t *out = hist_out + (size_t)p * n * n;
+            for (uint32_t i = 0; i < n * n; ++i) out[i] += h[i];
         }
-        std::vector<unsigned long long> h((size_t)n * n * n_problems);
-        HIP_TRY(hipMemcpy(h.data(), d + o_hist, hist_bytes, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < h.size(); ++i) hist_out[i] += h[i];
-        c->last_grid = (uint32_t)grid;
-        c->last_block = block;
-        c->last_lds = (uint32_t)lds;
-        std::snprintf(c->last_kernel, sizeof(c->last_kernel), "mcgp::race_kernel_reg_batch<%u>", n);
+        HIP_TRY(hipEventRecord(c->batch_stop, nullptr));
+        c->last_timer = kBatchTimer;
         return MCGP_OK;
     };
     return body();
@@ -1006,8 +1115,14 @@ int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out)
     if (device < 0 || device >= kMaxDevices) return fail(MCGP_E_BAD_ARG, "device index out of range");
     DeviceCtx &c = g_ctx[device];
     std::lock_guard<std::mutex> lock(c.mu);
-    if (!c.ready || c.last_timer < 0) return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
+    if (!c.ready || (c.last_timer < 0 && c.last_timer != kBatchTimer))
+        return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
     HIP_TRY(hipSetDevice(device));
+    if (c.last_timer == kBatchTimer) {                  // mcgp_run_batch: everything the call ran on the device
+        HIP_TRY(hipEventSynchronize(c.batch_stop));
+        HIP_TRY(hipEventElapsedTime(ms_out, c.batch_start, c.batch_stop));
+        return MCGP_OK;
+    }
     HIP_TRY(hipEventSynchronize(c.timer[c.last_timer].stop));
     HIP_TRY(hipEventElapsedTime(ms_out, c.timer[c.last_timer].start, c.timer[c.last_timer].stop));
     return MCGP_OK;
@@ -1038,7 +1153,8 @@ const char *mcgp_last_kernel_name(int32_t device)
 
 int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads, uint32_t *lds_bytes)
 {
-    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready || g_ctx[device].last_timer < 0)
+    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready ||
+        (g_ctx[device].last_timer < 0 && g_ctx[device].last_timer != kBatchTimer))
         return fail(MCGP_E_BAD_ARG, "no kernel launched on this device yet");
     if (grid_blocks) *grid_blocks = g_ctx[device].last_grid;
     if (block_threads) *block_threads = g_ctx[device].last_block;

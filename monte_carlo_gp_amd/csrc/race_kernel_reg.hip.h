@@ -169,6 +169,12 @@ constexpr int kWideBlockWaves = MCGP_WIDE_BLOCK_WAVES;
 // memory instead (normal53_rows, race_common.hip.h), which at 2^-32 per draw (a few wave-batches per 10^7 races) costs
 // nothing and keeps that path exercised.
 constexpr int kWideLdsRowsMax = 32 * 16;
+// A row takes 80 bytes of LDS, not 64: its four 16-byte pieces are fetched by four ds_read_b128, each lane its own row,
+// and a 16-lane group of that instruction is conflict-free only if its lanes hit 16 different 16-byte slots of the 256-byte
+// bank row.  At a stride of 64 bytes piece k of ANY row lies in one of 4 slots (4 r + k mod 16): 16 lanes in 4 slots,
+// 6 LDS cycles per group on average and 48 % of the kernel's LDS cycles spent on conflicts (profiles/r5_counters.json, first
+// version); at 80 bytes (5 r + k mod 16) every slot is reachable and the average is 3.
+constexpr int kNorm53LdsStride = 80;
 __host__ __device__ constexpr size_t wide_fixed_lds_bytes(int n, int waves)
 {
     return shared_lds_bytes_reg(n) - (size_t)kNormalRows * 16 + (size_t)waves * 64 * per_thread_lds_bytes_reg(n);
@@ -177,12 +183,12 @@ __host__ __device__ constexpr int wide_lds_rows(int n, int waves)
 {
     const size_t fixed = wide_fixed_lds_bytes(n, waves);
     const size_t room = kLdsPerCu - kLdsReserve > fixed ? kLdsPerCu - kLdsReserve - fixed : 0;
-    int rows = (int)(room / (size_t)kNormal53RowBytes) / 16 * 16;
+    int rows = (int)(room / (size_t)kNorm53LdsStride) / 16 * 16;
     return rows > kWideLdsRowsMax ? kWideLdsRowsMax : rows;
 }
 __host__ __device__ constexpr size_t wide_lds_bytes(int n, int waves)
 {
-    return wide_fixed_lds_bytes(n, waves) + (size_t)wide_lds_rows(n, waves) * kNormal53RowBytes;
+    return wide_fixed_lds_bytes(n, waves) + (size_t)wide_lds_rows(n, waves) * kNorm53LdsStride;
 }
 // ... and, behind the table rows, the 64-bit survival thresholds of the retirement draw (S_k per lap and driver, the same
 // for every race of the launch: reg_load_tables) when the race is short enough for them to fit -- a 20-car block has room
@@ -221,7 +227,7 @@ struct RegGeo {
     static constexpr uint32_t oNorm53 = oLast + (uint32_t)N * B * 8;
     static constexpr int kNorm53Rows = WIDE ? wide_lds_rows(N, WAVES) : 0;
     static constexpr int kNorm53First = kNormal53Rows - kNorm53Rows;
-    static constexpr uint32_t kBytes = oNorm53 + (uint32_t)kNorm53Rows * (uint32_t)kNormal53RowBytes;
+    static constexpr uint32_t kBytes = oNorm53 + (uint32_t)kNorm53Rows * (uint32_t)kNorm53LdsStride;
     // WIDE: [lap - 2][driver, padded to a multiple of 4] u64 survival thresholds of the retirement draw, if they fit
     static constexpr uint32_t oChain = kBytes;
     static constexpr uint32_t kChainStride = (uint32_t)((N + 3) & ~3) * 8u;
@@ -613,7 +619,8 @@ __device__ __forceinline__ void reg_load_tables(const KParams *__restrict__ P, u
     if constexpr (G::kWide) {
         // the rows of the binary64 inverse-normal table this block keeps in LDS (RegGeo: the table's last kNorm53Rows)
         double *t53 = reinterpret_cast<double *>(smem + G::oNorm53);
-        for (uint32_t i = tid; i < (uint32_t)G::kNorm53Rows * 8u; i += B) t53[i] = norm53[(uint32_t)G::kNorm53First * 8u + i];
+        for (uint32_t i = tid; i < (uint32_t)G::kNorm53Rows * 8u; i += B)
+            t53[(i >> 3) * (kNorm53LdsStride / 8) + (i & 7u)] = norm53[(uint32_t)G::kNorm53First * 8u + i];
         // the retirement chain of every driver (reference :190-197 drawn once per race, 64-bit form: S_2 = q,
         // S_{k+1} = floor(S_k q / 2^64), q = 2^64 - ceil(p 2^64)), one thread per driver; padding drivers get zeros
         if (G::chain_fits(P->total_laps)) {
@@ -731,7 +738,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     // indices, RegGeo::kNorm53First -- is flagged by hi < kRareHi and read from the table in device memory (normal53()).
     constexpr uint32_t kRareHi = (kNormal53HiBias + (uint32_t)(G::kNorm53First > 16 ? G::kNorm53First : 16)) << 16;
     [[maybe_unused]] auto norm53_row = [&](uint32_t hi, double (&c)[8]) {
-        const uint32_t a = ((hi >> 10) & ~63u) + (G::oNorm53 - (kNormal53HiBias + (uint32_t)G::kNorm53First) * 64u);
+        const uint32_t a = (hi >> 16) * (uint32_t)kNorm53LdsStride + (G::oNorm53 - (kNormal53HiBias + (uint32_t)G::kNorm53First) * (uint32_t)kNorm53LdsStride);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const f64x2 v = lds_ld_f64x2(a + 16u * k);
@@ -1802,24 +1809,29 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     }
 }
 
-template <int N>
-__global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
+// WAVES: the block shape.  The default is the one measured best for the field size (reg_block_waves); every field size is
+// also compiled in blocks of kSmallBlockWaves waves, whose LDS footprint is less than half a CU's: the shape the library
+// falls back to when the default block does not fit what the device (or a runtime that keeps some LDS to itself) offers.
+constexpr int kSmallBlockWaves = 4;
+template <int N, int WAVES = reg_block_waves(N)>
+__global__ void __launch_bounds__((RegGeo<N, WAVES>::B), reg_min_waves(N))
 race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                 uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                 uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,
                 uint32_t *__restrict__ ticket, uint32_t *__restrict__ retire_ws)
 {
+    using G = RegGeo<N, WAVES>;
     extern __shared__ __align__(16) unsigned char smem[];
     // host and kernel must agree on the geometry, and the rows are addressed by absolute LDS address
     // (race_isa.hip.h): a violation aborts the launch (a HIP error at the next synchronisation), never a silent result
-    if ((int)blockDim.x != RegGeo<N>::B || lds_base_of(smem) != 0u) __builtin_trap();
-    reg_load_tables<N>(P, smem, threadIdx.x);
+    if ((int)blockDim.x != G::B || lds_base_of(smem) != 0u) __builtin_trap();
+    reg_load_tables<N, G>(P, smem, threadIdx.x);
     __syncthreads();
     // retirement lists: one column per lane of the launch, N + 1 rows (reg_retire_ws_bytes)
-    reg_simulate<N>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
-                    retire_ws, (uint32_t)(gridDim.x * RegGeo<N>::B), (uint32_t)(blockIdx.x * RegGeo<N>::B));
+    reg_simulate<N, false, G>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, seed_lo, seed_hi, orders, fixed_grid, n_chunks,
+                              retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B));
     __syncthreads();
-    reg_flush_hist<N>(smem, threadIdx.x, hist);
+    reg_flush_hist<N, G>(smem, threadIdx.x, hist);
 }
 
 // The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): same phases, blocks of 8 waves at 2 waves per SIMD.

@@ -24,11 +24,38 @@ from __future__ import annotations
 
 import ctypes as C
 import random
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 
 from . import _native as N
+
+
+@dataclass
+class CarState:
+    """The reference's per-car record (:9-34), kept for callers that import it: same fields, same defaults, same
+    __post_init__.  Nothing here computes on it -- on the device a car is a binary64 `cumulative_time` and one packed
+    word (grid slot, tyre age or retirement lap, driver, compound, dirty-air / DRS / retired flags, dry compounds used:
+    csrc/race_kernel_reg.hip.h) in registers, and its `last_lap_time` a row of LDS; `position`, `pit_stops`,
+    `laps_completed`, `team` and `fuel_load` are inert or derivable in the reference's loop."""
+    driver: str
+    team: str
+    position: int
+    lap: int
+    tire_compound: str
+    tire_age: int
+    fuel_load: float
+    time_behind_leader: float
+    pit_stops: int
+    cumulative_time: float = 0.0
+    drs_enabled: bool = False
+    dnf: bool = False
+    used_compounds: set = field(default_factory=set)
+    laps_completed: int = 0
+    last_lap_time: float = 0.0
+
+    def __post_init__(self):
+        self.used_compounds.add(self.tire_compound)          # the starting compound counts as used (:31-34)
 
 
 @dataclass
@@ -319,8 +346,10 @@ def run_monte_carlo_batch(problems, n_simulations, device=0, set_pop=None):
 
     `problems`: a list of dicts with the keys `config` (RaceConfig) and run_monte_carlo's arguments `grid_probs`,
     `base_pace`, `tire_deg`, `driver_variance`, and optionally `driver_dnf_rates`, `seed`, `track_condition`,
-    `sim_offset`.  Returns a list of (probabilities as run_monte_carlo returns them, integer histogram [n, n]), one
-    per problem and bit-identical to running it alone.  Races of different field sizes go into one launch per size."""
+    `sim_offset`, `deviates` (32 or 53).  Returns a list of (probabilities as run_monte_carlo returns them, integer
+    histogram [n, n]), one per problem and bit-identical to running it alone.  Races of different field sizes go into
+    one launch per size; a problem the shared launch does not take (deviates = 53, or one only the generic kernel
+    serves) runs by itself inside the same call -- no problem can make another one fail."""
     set_pop = dict(set_pop or DEFAULT_SET_POP)
     lib = N.lib()
     n_simulations = int(n_simulations)
@@ -330,7 +359,7 @@ def run_monte_carlo_batch(problems, n_simulations, device=0, set_pop=None):
         if not (1 <= len(drivers) <= N.MAX_CARS):
             raise ValueError(f'number of drivers must be in [1, {N.MAX_CARS}], got {len(drivers)}')
         prob = _Problem(pr['config'], drivers, pr['base_pace'], pr['tire_deg'], pr['driver_variance'],
-                        pr.get('driver_dnf_rates'), pr.get('track_condition', 'dry'), set_pop)
+                        pr.get('driver_dnf_rates'), pr.get('track_condition', 'dry'), set_pop, pr.get('deviates', 32))
         g = RaceSimulator._grid_matrix({str(k): v for k, v in pr['grid_probs'].items()}, drivers)
         prepared.append((prob, g, RaceSimulator._resolve_seed(pr.get('seed')), int(pr.get('sim_offset', 0))))
     out = [None] * len(prepared)

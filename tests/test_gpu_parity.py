@@ -416,6 +416,89 @@ def test_a_season_of_races_in_one_launch(require_gpu):
     assert run_monte_carlo_batch([problem('S60', 1, 0)], 0)[0][0] == {}
 
 
+def test_a_batch_gives_every_problem_what_mcgp_run_would(require_gpu, monkeypatch):
+    """mcgp_run_batch = mcgp_run semantics (reference src/validation.py:179-185: a sweep is a loop over
+    independent predictions).  One call with 22 ordinary 20-car races, one only the generic kernel takes (X_all_attempt:
+    overtake_delta = -50) and one at reference width (deviates = 53): each gets the oracle's histogram -- the ordinary
+    ones from the shared launch, the other two from their own launches inside the call -- and the call's device time is
+    what mcgp_last_kernel_ms reports afterwards, on a context whose first call this may be."""
+    import ctypes as C
+    import json
+    from monte_carlo_gp_amd import RaceConfig, run_monte_carlo_batch, _native as N
+    with open(O.GOLDEN_DIR + '/fuzz_cases.json') as f:
+        fuzz = json.load(f)
+    names = ['S60', 'S78', 'S50', 'EVT', 'DMP', 'WET']
+    cases = {k: O.load_case(k) for k in names}
+    cases['X'] = fuzz['X_all_attempt']
+    plan = [(names[i % 6], 500 + 13 * i, 7 * i, 32) for i in range(22)]
+    plan.insert(5, ('X', 77, 3, 32))
+    plan.insert(11, ('S60', 78, 9, 53))
+    n_sims = 6000
+
+    def problem(name, seed, off, dev):
+        c = cases[name]
+        return dict(config=RaceConfig(**c['config']), grid_probs=c['grid_probs'], base_pace=c['base_pace'],
+                    tire_deg=c['tire_deg'], driver_variance=c['driver_variance'], driver_dnf_rates=c.get('driver_dnf_rates'),
+                    seed=seed, track_condition=c['track_condition'], sim_offset=off, deviates=dev)
+    set_pop = O.load_cases()['set_pop']
+    out = run_monte_carlo_batch([problem(*p) for p in plan], n_sims, device=0, set_pop=set_pop)
+    ms = C.c_float()
+    N.check(N.lib().mcgp_last_kernel_ms(0, C.byref(ms)))
+    assert 0.5 < ms.value < 200.0, ms.value
+    for (name, seed, off, dev), (probs, hist) in zip(plan, out):
+        ref = O.Problem(cases[name]).run(n_sims, rng=O.RNG_PHILOX53 if dev == 53 else O.RNG_PHILOX, seed=seed, sim_offset=off)['hist']
+        assert np.array_equal(hist, ref), (name, seed, dev)
+    # MCGP_FORCE_GENERIC=1 is honoured on this path too: every problem through the generic kernel, same results
+    monkeypatch.setenv('MCGP_FORCE_GENERIC', '1')
+    again = run_monte_carlo_batch([problem(*p) for p in plan[:4]], 1500, device=0, set_pop=set_pop)
+    assert N.lib().mcgp_last_kernel_name(0).decode() == 'mcgp::race_kernel'
+    monkeypatch.delenv('MCGP_FORCE_GENERIC')
+    for (name, seed, off, dev), (probs, hist) in zip(plan[:4], again):
+        assert np.array_equal(hist, O.Problem(cases[name]).run(1500, rng=O.RNG_PHILOX, seed=seed, sim_offset=off)['hist'])
+
+
+def test_a_device_with_less_lds_gets_small_blocks(require_gpu):
+    """The 20-car block fills the CU's LDS to the last half kilobyte (163 264 of 163 840 B).  A device or runtime that
+    offers less per block gets the same kernel in blocks of 4 waves: same results, the shape
+    visible in mcgp_last_launch_info / mcgp_last_kernel_name.  Run in child processes (the limit is read when the
+    device context is created): MCGP_LDS_PER_BLOCK = what the device reports minus 4 KB, and 80 KB; at 32 KB not even the
+    small block fits and the call fails with an error that says so."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes as C, numpy as np\n"
+        "sys.path.insert(0, 'tests')\n"
+        "import oracle_py as O\n"
+        "from helpers import product_run\n"
+        "from monte_carlo_gp_amd import _native as N\n"
+        "for name in ('S60', 'HET', 'N10'):\n"
+        "    case = O.load_case(name)\n"
+        "    hist, probs, orders = product_run(case, 3000, 42, sim_offset=5, orders=True)\n"
+        "    ref = O.Problem(case).run(3000, rng=O.RNG_PHILOX, seed=42, sim_offset=5, want_orders=True)\n"
+        "    assert np.array_equal(orders, ref['orders']) and np.array_equal(hist, ref['hist']), name\n"
+        "    g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()\n"
+        "    N.lib().mcgp_last_launch_info(0, C.byref(g), C.byref(b), C.byref(l))\n"
+        "    print(name, N.lib().mcgp_last_kernel_name(0).decode(), b.value, l.value)\n")
+    import os
+    for limit in (163840 - 4096, 81920):
+        env = dict(os.environ, MCGP_LDS_PER_BLOCK=str(limit))
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=O.ROOT, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = dict((ln.split()[0], ln.split()[1:]) for ln in r.stdout.strip().splitlines())
+        # default blocks: 20 cars 163 264 B (12 waves), 21 cars 157 168 B (11 waves), 10 cars 69 072 B (8 waves); a block that
+        # does not fit the limit is replaced by blocks of 4 waves, which always do
+        for name, n, default_bytes in (('S60', 20, 163264), ('HET', 21, 157168), ('N10', 10, 69072)):
+            small = default_bytes > limit
+            got = ' '.join(lines[name][:-2])
+            assert got == (f'mcgp::race_kernel_reg<{n}, 4>' if small else f'mcgp::race_kernel_reg<{n}>'), (limit, lines)
+            assert (lines[name][-2] == '256') == small and int(lines[name][-1]) <= limit, (limit, lines)
+            if not small:
+                assert int(lines[name][-1]) == default_bytes, lines
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, MCGP_LDS_PER_BLOCK='32768'),
+                       cwd=O.ROOT, timeout=600)
+    assert r.returncode != 0 and 'bytes of LDS' in r.stderr, r.stderr[-2000:]
+
+
 def test_more_than_eight_attempts_in_a_pass(require_gpu):
     """overtake_delta = 0: every pair with a pace advantage attempts, so most passes have a lane with more than the
     eight attempts the W plane holds and the wave takes the general path, eight at a time (reference :516-524)."""
