@@ -1866,6 +1866,52 @@ race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t si
 struct BatchItem {
     uint64_t sim_offset, seed;
 };
+// One problem of the batch on this block: tables, the block's share of the problem's chunks, histogram flush.  A function
+// of its own (MCGP_BATCH_CALL=1) so that the register allocator sees the race loop as it sees it in the single-problem kernel.
+#ifndef MCGP_BATCH_CALL
+#define MCGP_BATCH_CALL 0
+#endif
+// (a function's arguments arrive in vector registers; these are the same in every lane, which readfirstlane says)
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t x) { return (uint64_t)uniform_u32((uint32_t)x) | ((uint64_t)uniform_u32((uint32_t)(x >> 32)) << 32); }
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
+template <int N>
+#if MCGP_BATCH_CALL
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+void batch_problem(const KParams *__restrict__ P_, unsigned char *smem_, uint32_t *__restrict__ ticket_, uint64_t n_sims_,
+                   uint64_t sim_offset_, uint64_t seed_, uint32_t n_chunks_, uint32_t *__restrict__ retire_ws_,
+                   unsigned long long *__restrict__ hist_)
+{
+    using G = RegGeo<N>;
+#if MCGP_BATCH_CALL
+    const KParams *__restrict__ P = uniform_ptr(P_);
+    unsigned char *smem = uniform_ptr(smem_);
+    uint32_t *__restrict__ ticket = uniform_ptr(ticket_);
+    uint32_t *__restrict__ retire_ws = uniform_ptr(retire_ws_);
+    unsigned long long *__restrict__ hist = uniform_ptr(hist_);
+    const uint64_t n_sims = uniform_u64(n_sims_), sim_offset = uniform_u64(sim_offset_), seed = uniform_u64(seed_);
+    const uint32_t n_chunks = uniform_u32(n_chunks_);
+#else
+    const KParams *__restrict__ P = P_;
+    unsigned char *smem = smem_;
+    uint32_t *__restrict__ ticket = ticket_;
+    uint32_t *__restrict__ retire_ws = retire_ws_;
+    unsigned long long *__restrict__ hist = hist_;
+    const uint64_t n_sims = n_sims_, sim_offset = sim_offset_, seed = seed_;
+    const uint32_t n_chunks = n_chunks_;
+#endif
+    reg_load_tables<N>(P, smem, threadIdx.x);                    // (zeroes the LDS histogram)
+    __syncthreads();
+    reg_simulate<N>(P, smem, threadIdx.x, ticket, n_sims, sim_offset, (uint32_t)seed, (uint32_t)(seed >> 32),
+                    nullptr, nullptr, n_chunks, retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B));
+    __syncthreads();                                             // every wave's counts are in
+    reg_flush_hist<N>(smem, threadIdx.x, hist);
+    __syncthreads();                                             // (the flush reads what the next table load zeroes)
+}
 template <int N>
 __global__ void __launch_bounds__(RegGeo<N>::B, reg_min_waves(N))
 race_kernel_reg_batch(const KParams *__restrict__ P, const BatchItem *__restrict__ items, uint32_t n_problems,
@@ -1902,14 +1948,8 @@ race_kernel_reg_batch(const KParams *__restrict__ P, const BatchItem *__restrict
         p += found - visited;
         if (p >= n_problems) p -= n_problems;
         visited = found + 1u;
-        reg_load_tables<N>(P + p, smem, threadIdx.x);            // (zeroes the LDS histogram)
-        __syncthreads();
         const BatchItem it = items[p];
-        reg_simulate<N>(P + p, smem, threadIdx.x, tickets + p, n_sims, it.sim_offset, (uint32_t)it.seed, (uint32_t)(it.seed >> 32),
-                        nullptr, nullptr, n_chunks, retire_ws, (uint32_t)(gridDim.x * G::B), (uint32_t)(blockIdx.x * G::B));
-        __syncthreads();                                         // every wave's counts are in
-        reg_flush_hist<N>(smem, threadIdx.x, hist + (size_t)p * N * N);
-        __syncthreads();                                         // (the flush reads what the next table load zeroes)
+        batch_problem<N>(P + p, smem, tickets + p, n_sims, it.sim_offset, it.seed, n_chunks, retire_ws, hist + (size_t)p * N * N);
         p += 1u;
         if (p >= n_problems) p -= n_problems;
     }
