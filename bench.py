@@ -43,6 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np  # noqa: E402
 
 SIMS_PER_STEP = 10_000_000
+SWEEP_SIMS_PER_RACE = 10_000_000           # BASELINE configs[4]
 ALGORITHMIC_BYTES_PER_SIM = 20          # the n x u8 finishing order, SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TINST = 1024 * 2.4e9 / 2 / 1e12   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
@@ -187,6 +188,46 @@ def profiled_counters(workload, per_gpu, lib_overridden):
     return w, None
 
 
+def relaunch_command(argv, n_gpus, port=None):
+    """The torch.distributed.run command line that runs THIS script with one rank per GPU (what the driver itself uses
+    for N > 1), given the script's own arguments."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def gpu_initialised():
+    """True once this process has touched the GPU through torch (any earlier HIP call of the library is the caller's to know:
+    bench.py makes none before this check)."""
+    torch = sys.modules.get('torch')
+    return bool(torch is not None and torch.cuda.is_initialized())
+
+
+def self_launch(argv, n_gpus):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: run the launcher as a CHILD process with the same
+    arguments and relay its output -- the JSON line of rank 0 -- and its exit code.  A process that has initialised the
+    GPU must not do this (and never re-execs itself): on this pool replacing or forking such a process takes the machine
+    down, so the request is refused there."""
+    import subprocess
+    if gpu_initialised():
+        raise SystemExit('bench.py: refusing to start torch.distributed.run from a process that has already initialised the GPU; '
+                         'start bench.py through the launcher instead')
+    from monte_carlo_gp_amd import _native as N
+    N.build()                                   # one build before N ranks ask for it (no HIP call: make only)
+    cmd = relaunch_command(argv, n_gpus)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    print('bench.py: no launcher environment (WORLD_SIZE unset): starting ' + ' '.join(cmd[1:8]) + ' ... as a child process',
+          file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -200,6 +241,11 @@ def main():
     ap.add_argument('--deviates', type=int, default=32, choices=(32, 53),
                     help='53: the timed steps run at the reference\'s deviate width (race_kernel_reg_wide; tools/profile.sh)')
     args = ap.parse_args()
+
+    # started as `python bench.py --gpus N` with no launcher around it: become the launcher's parent (before anything here
+    # imports torch or touches the GPU)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -416,16 +462,64 @@ def main():
         # and binary64 normals (mcgp_config.deviates = MCGP_DEVIATES_53; bit-identical to the oracle's PHILOX53 back-end)
         w53 = run_workload(args.workload, 3, 1, deviates=53)
         out['deviates53'] = {'value': w53['total'] / w53['elapsed'], 'unit': 'race-simulations/s', 'steps': 3,
-                             'kernel_ms_avg': w53['kernel_ms'], 'kernel': w53['kernel'],
+                             'kernel_ms_avg': w53['kernel_ms'], 'kernel': w53['kernel'], 'launch': w53['launch'],
                              'slowdown_vs_32bit_deviates': w53['kernel_ms'] / kavg_ms,
                              'note': 'every draw keeps the 32-bit word as its leading bits and takes 21 more from a companion '
-                                     'Philox block; normals from a degree-7 binary64 table in device memory; effect on '
-                                     'results: profiles/r4_deviate_bias.txt (GPU, 10^9 simulations)'}
+                                     'Philox block -- computed only where the word alone does not decide (normals always; a '
+                                     'Bernoulli draw when the word equals the leading word of its threshold, one in 2^32); '
+                                     'binary64 normals from a degree-7 table whose rows sit in LDS; bit-identical to the '
+                                     "oracle's PHILOX53 back-end; effect on results: profiles/r4_deviate_bias.txt (GPU, 10^9 simulations)"}
+        # its own roofline block: the same binding bound, counters of the reference-width kernel
+        pcw, why_w = profiled_counters(args.workload + '_wide', per_gpu, bool(os.environ.get('MCGP_LIB')))
+        roof53 = {'bound': 'valu-issue', 'achieved': None, 'peak': VALU_PEAK_TINST, 'unit': 'T wave-instructions/s', 'frac': None,
+                  'traffic': None, 'kernel': w53['kernel'], 'kernel_ms_avg': w53['kernel_ms'], 'counters_note': why_w}
+        if pcw:
+            rate53 = pcw['SQ_INSTS_VALU'] / (w53['kernel_ms'] * 1e-3) / 1e12
+            roof53.update({'achieved': rate53, 'frac': rate53 / VALU_PEAK_TINST, 'traffic': pcw.get('hbm_bytes_per_launch'),
+                           'frac_at_fp64_rate': rate53 / VALU_PEAK_TINST_4CYCLE, 'valu_insts_per_launch': pcw['SQ_INSTS_VALU'],
+                           'active_lane_ratio': pcw.get('active_lane_ratio'), 'waves_per_simd': pcw.get('waves_per_simd'),
+                           'issue_frac': pcw.get('issue_frac'), 'wait_frac': pcw.get('wait_frac'),
+                           'lds_conflict_share': (pcw['SQ_LDS_BANK_CONFLICT'] / pcw['SQ_LDS_IDX_ACTIVE']
+                                                  if pcw.get('SQ_LDS_IDX_ACTIVE') else None),
+                           'scratch_bytes_per_lane': int(pcw.get('kernel', {}).get('Scratch_Size', 0) or 0),
+                           'source_hash': pcw.get('source_hash')})
+            if pcw.get('active_lane_ratio'):
+                roof53['frac_useful_lanes'] = roof53['frac'] * pcw['active_lane_ratio']
+        out['deviates53']['roofline'] = roof53
+        out['value_at_reference_width'] = out['deviates53']['value']
         bytes_written = per_gpu * wo['n']
         out['orders_mode'] = {'value': wo['total'] / wo['elapsed'], 'unit': 'race-simulations/s', 'steps': 3,
                               'kernel_ms_avg': wo['kernel_ms'], 'bytes_per_launch': bytes_written,
                               'write_gb_per_s': bytes_written / (wo['kernel_ms'] * 1e-3) / 1e9,
                               'frac_of_hbm_peak': bytes_written / (wo['kernel_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if not args.no_extras:
+        # BASELINE configs[4]: the 2024 calendar (24 races) x 10^7 simulations each through the code `cli backtest` runs
+        # (reference src/validation.py:161-209): races round-robin over ranks, no collective in the data path, one
+        # all_gather_object of the per-race rows at the end.  Wall time between barrier + synchronize pairs, MAX over ranks.
+        from monte_carlo_gp_amd.cli import backtest, backtest_jobs
+        n_races = len(backtest_jobs([2024], 42))
+        sync()
+        t0 = time.perf_counter()
+        res = backtest([2024], seed=42, n_simulations=SWEEP_SIMS_PER_RACE, device=local_rank, rank=rank, world=world)
+        sync()
+        dt = time.perf_counter() - t0
+        if grouped:
+            t = torch.tensor([dt], dtype=torch.float64, device='cpu' if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            assert res['n_races'] == n_races
+            out.setdefault('workloads', {})['sweep24'] = {
+                'metric': f'backtest sweep: {n_races} races of the 2024 calendar x {SWEEP_SIMS_PER_RACE} simulations each '
+                          '(BASELINE configs[4]; cli.backtest)',
+                'wall_seconds': dt, 'value': n_races * SWEEP_SIMS_PER_RACE / dt, 'unit': 'race-simulations/s',
+                'n_races': n_races, 'simulations_per_race': SWEEP_SIMS_PER_RACE, 'kernel_launches': n_races,
+                'launches_per_rank': -(-n_races // world), 'n_gpus': world,
+                'win_brier': res['win_brier'], 'pole_brier': res['pole_brier'], 'podium_accuracy': res['podium_accuracy'],
+                'reference_comparable': res['reference_comparable'],
+                'note': 'one launch per race (above 10^6 simulations a race fills the device by itself; at the reference\'s 10^4 the '
+                        'races of a rank share one launch); host inputs, Elo evolution and scoring included in the wall time; '
+                        'outcomes are a hand-entered results file: scores are not comparable with a live reference run'}
     gpu_seconds = time.perf_counter() - t_gpu0           # every GPU leg of this run: timed steps, warm-up, side lines
     # which device each rank ran on: N ranks on N DISTINCT GPUs is a fact of the run, printed, not an assumption
     props = torch.cuda.get_device_properties(dev)

