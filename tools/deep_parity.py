@@ -3,6 +3,7 @@
 at sizes well beyond the test suite's (rare paths: re-sort fallback, equal-time ties, event storms, mass retirements).
 
     python tools/deep_parity.py [sims per fuzz configuration] [sims per golden case]  > profiles/r2_deep_parity.txt
+    DEVIATES=53 ...: the reference-width kernel against the oracle's PHILOX53 back-end (configurations the register kernel takes)
 
 Test infrastructure (uses the oracle as the checker); prints one line per configuration and a summary."""
 import json
@@ -20,6 +21,10 @@ import oracle_py as O  # noqa: E402
 from helpers import product_run  # noqa: E402
 
 
+DEVIATES = int(os.environ.get('DEVIATES', '32'))
+RNG = O.RNG_PHILOX53 if DEVIATES == 53 else O.RNG_PHILOX
+
+
 def oracle_orders(case, n, seed, threads=16):
     chunk = (n + threads - 1) // threads
 
@@ -28,7 +33,7 @@ def oracle_orders(case, n, seed, threads=16):
         cnt = max(0, min(chunk, n - lo))
         if cnt == 0:
             return np.zeros((0, len(case['grid_probs'])), np.uint8)
-        return O.Problem(case).run(cnt, rng=O.RNG_PHILOX, seed=seed, sim_offset=lo, want_orders=True)['orders']
+        return O.Problem(case).run(cnt, rng=RNG, seed=seed, sim_offset=lo, want_orders=True)['orders']
     with ThreadPoolExecutor(threads) as ex:
         return np.vstack(list(ex.map(part, range(threads))))
 
@@ -41,8 +46,11 @@ def main():
     jobs = [(name, O.load_case(name), 42, n_gold) for name in ('S60', 'S78', 'S50', 'EVT', 'HET', 'DMP', 'WET', 'N10')]
     jobs += [(name, c, c['seed'], n_fuzz) for name, c in fuzz.items()]
     bad_total, sims_total, t0 = 0, 0, time.time()
+    print(f'deviates = {DEVIATES}', flush=True)
     for name, case, seed, n in jobs:
-        hist, _, orders = product_run(case, n, seed, orders=True)
+        if DEVIATES == 53 and case['config']['overtake_delta'] < 0:
+            continue                                  # (generic-kernel problems have no reference-width build)
+        hist, _, orders = product_run(case, n, seed, orders=True, deviates=DEVIATES)
         ref = oracle_orders(case, n, seed)
         bad = int((orders != ref).any(axis=1).sum())
         bad_total += bad
