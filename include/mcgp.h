@@ -143,9 +143,11 @@ int32_t mcgp_run_device(const mcgp_config *cfg, const mcgp_drivers *drv, const d
  * that size a launch lasts as long as one race of one lane and most of the device idles.  n_problems races of the same
  * field size n, n_sims simulations each: cfgs[p], drvs[p], grid_probs[p] (n x n) as for mcgp_run, simulation ids
  * sim_offsets[p] .. sim_offsets[p] + n_sims - 1 (NULL: 0) under seeds[p]; hist_out = [n_problems][n][n], ACCUMULATED
- * into.  Every problem's histogram is bit-identical to what mcgp_run gives for it alone.  Host buffers in and out,
- * blocking.  MCGP_E_BAD_ARG also for a problem outside the register kernel's domain (lap times near zero: mcgp_run
- * serves those on its second kernel). */
+ * into.  Every problem gets exactly what mcgp_run would give it, error or histogram (a sweep of the reference is a loop
+ * over independent predictions): the problems the shared launch takes go into it; a problem at deviates =
+ * MCGP_DEVIATES_53, or one only the second kernel serves (lap times near zero, a negative overtake_delta), or every
+ * problem under MCGP_FORCE_GENERIC=1, runs by itself inside the same call.  Host buffers in and out, blocking.
+ * mcgp_last_kernel_ms afterwards = the device time of everything the call ran. */
 int32_t mcgp_run_batch(uint32_t n_problems, const mcgp_config *cfgs, const mcgp_drivers *drvs,
                        const double *const *grid_probs, uint32_t n, uint64_t n_sims, const uint64_t *sim_offsets,
                        const uint64_t *seeds, int32_t device, uint64_t *hist_out);
@@ -207,7 +209,11 @@ int32_t mcgp_elo_season(uint32_t n_drivers, uint32_t n_events, const int32_t *ki
  *                          most recently used streams per device;
  *   mcgp_last_kernel_ms    the most recent call on `device` by any thread --
  *                          meaningful when one thread drives the device.
- * mcgp_last_launch_info / mcgp_last_kernel_name describe that same most recent call. */
+ * mcgp_last_launch_info / mcgp_last_kernel_name describe that same most recent call -- including the block SHAPE the
+ * launch ended up with: the register kernel's default block fills a CU's LDS almost completely (163 264 of 163 840 B at
+ * 20 cars); on a device or under a runtime that offers less per block the launch falls back, by itself, to the same
+ * kernel in blocks of 4 waves (block_threads = 256, name "mcgp::race_kernel_reg<n, 4>"), same results, about 15 % slower.
+ * If not even that block fits, the call fails with MCGP_E_HIP and a message that names both sizes. */
 int32_t mcgp_last_kernel_ms(int32_t device, float *ms_out);
 int32_t mcgp_stream_kernel_ms(int32_t device, void *stream, float *ms_out);
 int32_t mcgp_last_launch_info(int32_t device, uint32_t *grid_blocks, uint32_t *block_threads,

@@ -26,11 +26,13 @@ def main():
         m = re.search(r'// ---- (.+?) ----\s*$', line)
         if m and first and not last: sections.append((i, m.group(1)[:48]))
     sections = [(first, 'lap loop head')] + sections
-    inside, cur = False, 0
+    inside, cur, first_fn = False, 0, None
     ops = collections.Counter()
     by_sec = collections.defaultdict(collections.Counter)
     for line in open(out):
-        if re.match(r'_ZN4mcgp\w+:', line): inside = symbol in line
+        if re.match(r'_ZN4mcgp\w+:', line):
+            inside = symbol in line and first_fn in (None, line)      # (the first instantiation: the default block shape)
+            if inside: first_fn = line
         if line.startswith('.Lfunc_end'): inside = False
         s = line.strip()
         m = re.match(r'\.loc\s+(\d+)\s+(\d+)', s)

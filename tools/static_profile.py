@@ -56,10 +56,12 @@ def main():
     marks = regions()
     files, cur = {}, (None, 0)
     counts = collections.OrderedDict()
-    inside = False
+    inside, first_fn = False, None
     for line in open(out):
         if re.match(r'_ZN4mcgp\w+:', line):
-            inside = symbol in line
+            inside = symbol in line and first_fn in (None, line)      # (the first instantiation: the default block shape)
+            if inside:
+                first_fn = line
         if line.startswith('.Lfunc_end'):
             inside = False
         s = line.strip()

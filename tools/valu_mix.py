@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Instruction-class mix of the register kernel's lap loop (N = 20) and the VALU issue ceiling it implies.
 
-    python tools/valu_mix.py [listing.s]      (default: compiles reg_inst.hip with -gline-tables-only)   -> profiles/r4_valu_mix.json
+    TAG=r5 python tools/valu_mix.py [listing.s]      (default: compiles reg_inst.hip with -gline-tables-only)   -> profiles/<TAG>_valu_mix.json
 
-Classes and their cost come from tools/valu_peak.hip (profiles/r3_valu_peak.json, wall-clock measurements; the 4-waves-per-SIMD column is used: 2, 4 and 8 agree within 3 %): binary64 operations and every VOP3-encoded (`_e64`, three-operand or SGPR-mask) or 64-bit integer
+Classes and their cost come from tools/valu_peak.hip (profiles/<TAG>_valu_peak.json if that round re-took it, else profiles/r3_valu_peak.json; wall-clock measurements; the 4-waves-per-SIMD column is used: 2, 4 and 8 agree within 3 %): binary64 operations and every VOP3-encoded (`_e64`, three-operand or SGPR-mask) or 64-bit integer
 instruction occupy a SIMD for ~4.15 cycles per wave64 instruction; VOP1 / VOP2 32-bit instructions (`_e32`) for ~2.2.
 Weights are STATIC instruction counts of the lap loop (straight-line code for the most part; the rarely executed general
 paths -- transposition sort, >8 attempts -- are left out by source line).  Not product code."""
@@ -19,6 +19,8 @@ SRC = os.path.join(ROOT, 'monte_carlo_gp_amd', 'csrc', 'race_kernel_reg.hip.h')
 
 
 def main():
+    tag = os.environ.get('TAG', 'r5')
+    peak_file = f'{tag}_valu_peak.json' if os.path.exists(os.path.join(ROOT, 'profiles', f'{tag}_valu_peak.json')) else 'r3_valu_peak.json'
     path = sys.argv[1] if len(sys.argv) > 1 else '/tmp/reg20_lines.s'
     if len(sys.argv) <= 1:
         subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off',
@@ -40,7 +42,7 @@ def main():
     # the listing holds three kernels (default, reference-width, batch): the default one only
     text = open(path).read()
     funcs = re.split(r'\n(?=_ZN4mcgp\w+:)', text)
-    body = next(f for f in funcs if f.startswith('_ZN4mcgp15race_kernel_regILi20'))
+    body = next(f for f in funcs if f.startswith('_ZN4mcgp15race_kernel_regILi20'))      # (the first one: the default block shape)
     cur, cold, classes, ops, fine = None, False, collections.Counter(), collections.Counter(), collections.Counter()
     for line in body.split('\n'):
         s = line.strip()
@@ -62,7 +64,7 @@ def main():
              'mad_u64' if op.startswith('v_mad_u64') else 'other 4-cycle' if four else '2-cycle'] += 1
         ops[op] += 1
     n4, n2 = classes['4-cycle class'], classes['2-cycle class']
-    peak = json.load(open(os.path.join(ROOT, 'profiles', 'r3_valu_peak.json')))['waves_per_simd']['4']
+    peak = json.load(open(os.path.join(ROOT, 'profiles', peak_file)))['waves_per_simd']['4']
     c4 = sum(peak[k] for k in ('v_add_f64', 'v_mul_f64', 'v_min_f64', 'v_bfe_u32', 'v_and_or_b32', 'v_cndmask_b32_e64 (SGPR mask)')) / 6
     c2 = sum(peak[k] for k in ('v_and_b32', 'v_xor_b32', 'v_add_u32')) / 3
     mean = (n4 * c4 + n2 * c2) / (n4 + n2)
@@ -74,7 +76,7 @@ def main():
     # The same mix at the kernel's OWN occupancy (N = 20: one block of 768 threads, 3 waves per SIMD), where the measured costs
     # are higher for several classes: a VOP2 instruction 2.85 cycles instead of 2.25, a compare 5.4, a 64-bit conversion 5.1,
     # v_mad_u64_u32 5.65 (profiles/r3_valu_peak.json, column "3 (one block of 768)").
-    p3 = json.load(open(os.path.join(ROOT, 'profiles', 'r3_valu_peak.json')))['waves_per_simd']['3 (one block of 768)']
+    p3 = json.load(open(os.path.join(ROOT, 'profiles', peak_file)))['waves_per_simd']['3 (one block of 768)']
     cost3 = {'compare': (p3['v_cmp_gt_f64 (vcc)'] + p3['v_cmp_lt_u32 (vcc)']) / 2, 'convert64': p3['v_cvt_f64_u32'],
              'mad_u64': p3['v_mad_u64_u32'],
              'other 4-cycle': sum(p3[k] for k in ('v_add_f64', 'v_mul_f64', 'v_min_f64', 'v_bfe_u32', 'v_and_or_b32', 'v_cndmask_b32_e64 (SGPR mask)')) / 6,
@@ -85,8 +87,8 @@ def main():
     sys.path.insert(0, ROOT)
     from monte_carlo_gp_amd import _native as N
     out['source_hash'] = N.source_hash()
-    out['costs_from'] = 'profiles/r3_valu_peak.json (tools/valu_peak.hip), 4 waves per SIMD'
-    with open(os.path.join(ROOT, 'profiles', 'r4_valu_mix.json'), 'w') as f:
+    out['costs_from'] = f'profiles/{peak_file} (tools/valu_peak.hip), 4 waves per SIMD'
+    with open(os.path.join(ROOT, 'profiles', f'{tag}_valu_mix.json'), 'w') as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
