@@ -22,7 +22,7 @@ The JSON line printed by rank 0 carries, besides the contract fields,
                  utilisation on this hardware (it reads 1.07 for this kernel); `traffic` = HBM bytes per
                  launch from the PMC passes; roofline.hbm_nominal = the 20 algorithmic bytes per simulation
                  against the 8 TB/s HBM peak -- evidence that the path is NOT memory bound.  Counters are quoted only
-                 when profiles/r4_counters.json carries the source hash the loaded binary reports (else null, reason in
+                 when profiles/r5_counters.json carries the source hash the loaded binary reports (else null, reason in
                  roofline.counters_note)
   workloads.S78  BASELINE configs[2] (78-lap Monaco parameters), three steps in the same run        (N = 1 only)
   orders_mode    the same workload with the 20 B per simulation actually written                    (N = 1 only)
@@ -52,8 +52,8 @@ VALU_PEAK_TINST = 1024 * 2.4e9 / 2 / 1e12   # 256 CUs x 4 SIMD-32, one wave64 VA
 # rate for every instruction; with the 2-cycle class in the mix it overshoots 1 -- 1.07 for the S60 kernel -- and is
 # quoted as `valu_busy_profiled` for reference only.)
 VALU_PEAK_TINST_4CYCLE = 1024 * 2.4e9 / 4 / 1e12
-COUNTERS_FILE = 'r4_counters.json'
-MIX_FILE = 'r4_valu_mix.json'
+COUNTERS_FILE = 'r5_counters.json'
+MIX_FILE = 'r5_valu_mix.json'
 
 
 def load_workload(name):
