@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic A/B of kernel variants on ONE GPU box (device-to-device variance is several %).
 #   tools/ablate.sh build   (in the build container: hipcc cross-compiles)  -> abl/libmcgp_<variant>.so
-#   tools/ablate.sh run     (on the GPU box, via gpurun)                    -> gpurun_out/ablate.txt
+#   tools/ablate.sh run     (on the GPU box, via gpurun)                    -> gpurun_out/ablate.txt   (DEV=53: the reference-width kernel)
 # VARIANTS are -DMCGP_<name>=<value> switches of race_kernel_reg.hip.h:
 #   DUP=k   run section k twice (idempotent, results unchanged): its cost shows as a time difference
 #           (1 sorting network after the lap step, 4 _update_positions, 8 re-sort after an overtake pass, 16 event Philox block)
@@ -27,7 +27,7 @@ run)
   : > $out
   for rep in 1 2; do
     for v in $VARIANTS; do
-      ms=$(MCGP_LIB=$PWD/abl/libmcgp_${v//=/_}.so MCGP_BENCH_NOCHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras \
+      ms=$(MCGP_LIB=$PWD/abl/libmcgp_${v//=/_}.so MCGP_BENCH_NOCHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --deviates ${DEV:-32} \
            --sims-per-step ${SIMS:-4000000} 2>/dev/null | python -c "import json,sys; print(json.load(sys.stdin)['roofline']['kernel_ms_avg'])")
       echo "$v kernel_ms=$ms" | tee -a $out
     done
