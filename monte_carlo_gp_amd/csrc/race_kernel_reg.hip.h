@@ -1872,7 +1872,14 @@ struct BatchItem {
 #define MCGP_BATCH_CALL 0
 #endif
 // (a function's arguments arrive in vector registers; these are the same in every lane, which readfirstlane says)
-__device__ __forceinline__ uint32_t uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+#else
+    return x;                                   // (the host debugging build: one thread at a time)
+#endif
+}
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x) { return (uint64_t)uniform_u32((uint32_t)x) | ((uint64_t)uniform_u32((uint32_t)(x >> 32)) << 32); }
 template <typename T>
 __device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
