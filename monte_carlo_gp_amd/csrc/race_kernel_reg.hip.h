@@ -155,13 +155,24 @@ __host__ __device__ constexpr size_t reg_retire_ws_bytes(int n, size_t lanes) { 
 
 // (WAVES: the default is the block shape measured best for the field size; the reference-width build runs at 2 waves per
 //  SIMD -- 256 registers instead of 168, which its binary64 deviates want -- in blocks of 8 waves)
-#ifndef MCGP_WIDE_BLOCK_WAVES
-#define MCGP_WIDE_BLOCK_WAVES 8
+// The reference-width build at 3 waves per SIMD (168 registers, as the default build at up to 22 cars): its lap step is
+// ordered so that a batch's four deviates are FINISHED before the batch's slots issue their LDS gathers -- the sixteen
+// registers of a table row and the sixty of the gathered values are then never alive together --, table rows are fetched
+// one at a time, and the two rare paths (a table row the block does not hold in LDS; the exact 53-bit overtake pass) are
+// out of line (normal53_batch_from_memory, wide_pass_exact_fn), so that their registers are not the race loop's to pay
+// for.  Same-box A/B against blocks of 8 waves at 2 per SIMD with the default ordering (profiles/r5_ab.txt): 10 cars -18 %,
+// 16 -12 %, 18 -9.5 %, 19 -7 %, 20 -6.5 % (S78 -4 %), 21 +0.4 %, 22 -2.8 %.  MCGP_WIDE_LEAN=0 (diagnostic builds) keeps every
+// field size at 2 waves per SIMD, gathers first, two rows at a time.
+#ifndef MCGP_WIDE_LEAN
+#define MCGP_WIDE_LEAN 1
 #endif
-#ifndef MCGP_WIDE_MIN_WAVES
-#define MCGP_WIDE_MIN_WAVES 2          // waves per SIMD the reference-width build is compiled for (register budget 512 / this)
-#endif
+// MCGP_WIDE_BLOCK_WAVES / MCGP_WIDE_MIN_WAVES (diagnostic builds): a fixed block shape / register budget for every field size
+// instead of the choice of wide_block_waves() / wide_min_waves() below.
+#ifdef MCGP_WIDE_BLOCK_WAVES
 constexpr int kWideBlockWaves = MCGP_WIDE_BLOCK_WAVES;
+#else
+constexpr int kWideBlockWaves = 0;             // chosen per field size
+#endif
 // The reference-width build keeps the binary64 inverse-normal table (normal53_table.h: 784 rows of 8 coefficients, 64 B
 // each) in LDS, behind the per-lane planes, instead of the 7 KB binary32 table it has no use for: as many of the table's
 // LAST rows -- the cells of the largest tail indices -- as fit beside the block's other data, in whole octaves of 16 rows,
@@ -241,13 +252,31 @@ struct RegGeo {
     static_assert(kBytes + kLdsReserve <= kLdsPerCu, "block does not fit LDS");
     static_assert(oLast < 65536, "row bases must fit the DS immediate offset");
 };
-// waves per block of the reference-width build: 8 (one block per CU at 2 waves per SIMD) where the block's rows fit the
-// CU's LDS, fewer for the largest fields (31 cars and more)
+// Waves per block of the reference-width build (one block per CU).  The lean ordering of its lap step (MCGP_WIDE_LEAN) fits
+// the 168 registers of 3 waves per SIMD, so the block is as large as the LDS allows while still holding kWideMinLdsRows
+// rows of the table -- below that a batch of deviates leaves the LDS rows too often: 12 or 11 waves up to 20 cars, 10 at 21
+// and 22 --; without room for more than 8 waves (23 cars and more), or without the lean ordering, 8 waves at 2 per SIMD
+// (256 registers), fewer for the largest fields (31 cars and more).
+constexpr int kWideMinLdsRows = 14 * 16;
 __host__ __device__ constexpr int wide_block_waves(int n)
 {
-    int w = kWideBlockWaves;
+    if (kWideBlockWaves == 0 && MCGP_WIDE_LEAN && n <= 22) {        // (23 cars and more: the default build itself runs at 2 waves per SIMD)
+        for (int w = 12; w > 8; --w)
+            if (wide_fixed_lds_bytes(n, w) + kLdsReserve <= kLdsPerCu && wide_lds_rows(n, w) >= kWideMinLdsRows) return w;
+    }
+    int w = kWideBlockWaves ? kWideBlockWaves : 8;
     while (w > 1 && wide_fixed_lds_bytes(n, w) + kLdsReserve > kLdsPerCu) --w;
     return w;
+}
+// waves per SIMD it is compiled for (register budget 512 / this)
+__host__ __device__ constexpr int wide_min_waves(int n)
+{
+#ifdef MCGP_WIDE_MIN_WAVES
+    (void)n;
+    return MCGP_WIDE_MIN_WAVES;
+#else
+    return wide_block_waves(n) > 8 ? 3 : 2;
+#endif
 }
 template <int N>
 using WideGeo = RegGeo<N, wide_block_waves(N), true>;
@@ -692,6 +721,106 @@ __device__ __forceinline__ void reg_flush_hist(unsigned char *smem, uint32_t tid
     }
 }
 
+// (a function's arguments arrive in vector registers; these are the same in every lane, which readfirstlane says)
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+#else
+    return x;                                   // (the host debugging build: one thread at a time)
+#endif
+}
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t x) { return (uint64_t)uniform_u32((uint32_t)x) | ((uint64_t)uniform_u32((uint32_t)(x >> 32)) << 32); }
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
+// the rare path of a batch's deviates (a table row the block does not hold in LDS), out of line: all four from the table
+// in device memory
+struct Deviates4 {
+    double z[4];
+};
+__device__ __attribute__((noinline)) inline Deviates4 normal53_batch_from_memory(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                                                                               uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
+                                                                               const double *tab_)
+{
+    const double *tab = reinterpret_cast<const double *>(uniform_u64(reinterpret_cast<uint64_t>(tab_)));
+    Deviates4 r;
+    r.z[0] = normal53(w0, x0, tab);
+    r.z[1] = normal53(w1, x1, tab);
+    r.z[2] = normal53(w2, x2, tab);
+    r.z[3] = normal53(w3, x3, tab);
+    return r;
+}
+
+// ... and the exact 53-bit decision of one overtake pass (reg_simulate, overtakes), out of line: the field's pk words go in
+// by value, everything else it reads is in the block's LDS tables.  Returns bit i = the attempt at pair i succeeds.
+template <int N>
+struct PkWords {
+    uint32_t v[N];
+};
+template <int N, class G>
+__device__ __attribute__((noinline)) uint32_t wide_pass_exact_fn(PkWords<N> field, double od31, uint32_t lap, uint32_t pass, uint32_t c0l,
+                                                                 uint32_t c1l, uint32_t k0l_, uint32_t k1l_, uint32_t tid)
+{
+    constexpr int B = G::B;
+    const uint32_t tid4 = tid * 4u;
+    const uint32_t k0l = uniform_u32(k0l_), k1l = uniform_u32(k1l_);          // (the key is the same in every lane)
+    const uint32_t (&pk)[N] = field.v;
+    auto w_row_ = [&](int r) -> uint32_t { return G::oW + (uint32_t)r * (B * 4) + tid4; };
+    uint32_t hits53 = 0u;
+    uint64_t thr64[N];
+    uint32_t cand = 0u;
+    {
+        double pace_prev = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const f64x2 bd = lds_ld_f64x2(G::oDrvB + pk_slot16(pk[i]));
+            const double pace = bd.x + (double)(pk[i] & k3AgeMask) * bd.y;
+            thr64[i] = 0ull;
+            if (i > 0) {
+                const double dl = (pace_prev - pace) + lds_ld<double>(G::oDrsB + (pk[i] & k3Drs));
+                const bool c = dl > od31;                                           // :522 (NaN: retired)
+                double x = ceil_f64(dl * 0x1p21);
+                x = x < 0x1p52 ? x : 0x1p52;
+                const uint32_t xh = c ? cvt_u32_f64_sat(x * 0x1p-32) : 0u;
+                const uint32_t xl = c ? cvt_u32_f64_sat(x - (double)xh * 0x1p32) : 0u;
+                thr64[i] = ((uint64_t)xh << 32) | (uint64_t)xl;
+                cand |= c ? (1u << i) : 0u;
+            }
+            pace_prev = pace;
+        }
+    }
+    uint32_t rest = cand;
+#pragma unroll 1
+    for (int chunk = 0; MCGP_ANY(rest != 0u); ++chunk) {
+        uint32_t m = rest;                                  // `rest` without its 4 lowest set bits
+#pragma unroll 1
+        for (int k = 0; k < 4 && m != 0u; ++k) m &= m - 1u;
+        const uint32_t cur = rest & ~m;                     // attempts 4 chunk .. 4 chunk + 3
+        uint32_t o0, o1, o2, o3;
+        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + chunk), k0l, k1l, o0, o1, o2, o3);
+        lds_st<uint32_t>(w_row_(0), o0);
+        lds_st<uint32_t>(w_row_(1), o1);
+        lds_st<uint32_t>(w_row_(2), o2);
+        lds_st<uint32_t>(w_row_(3), o3);
+        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | kCompanion | (uint32_t)(8 * pass + chunk), k0l, k1l, o0, o1, o2, o3);
+        lds_st<uint32_t>(w_row_(4), o0);
+        lds_st<uint32_t>(w_row_(5), o1);
+        lds_st<uint32_t>(w_row_(6), o2);
+        lds_st<uint32_t>(w_row_(7), o3);
+        uint32_t h = 0u;
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            // (a pair outside `cur` reads some other words, or just past the plane: masked out below)
+            const uint32_t r = (uint32_t)__popc(cur & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4;
+            const uint64_t u = uniform53(lds_ld<uint32_t>(G::oW + r), lds_ld<uint32_t>(G::oW + (uint32_t)(4 * B * 4) + r));
+            h |= u < thr64[i] ? (1u << i) : 0u;
+        }
+        hits53 |= h & cur;
+        rest = m;
+    }
+    return hits53;
+}
+
 // Phase 2: the simulations, one full race per lane.  The unit of work is a WAVE-CHUNK of 64 consecutive simulations,
 // and every wave of the launch claims its next chunk from one ticket counter in device memory (zeroed by the host
 // before the launch) until the chunks run out: a wave that runs faster than its neighbours takes more of them instead
@@ -715,6 +844,8 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
     constexpr int B = G::B;
     // slots in flight together in the lap step / in an overtake pass (the reference-width build has 256 registers to spend)
     constexpr int kStepBatch = WIDE ? MCGP_WIDE_STEP_BATCH : MCGP_STEP_BATCH;
+    // (WIDE, compiled for 3 waves per SIMD: deviates first, gathers last, one table row at a time -- see MCGP_WIDE_LEAN)
+    constexpr bool kLean = WIDE && wide_min_waves(N) >= 3;
     constexpr int kPaceBatch = WIDE ? MCGP_WIDE_PACE_BATCH : MCGP_PACE_BATCH;
     static_assert(kStepBatch % 4 == 0, "a Philox block serves four consecutive places");
     const uint32_t tid4 = tid * 4u, tid8 = tid * 8u;
@@ -1410,9 +1541,11 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 for (int i0 = 0; i0 < ((MCGP_SKIP & 64) ? 0 : N); i0 += kStepBatch) {
                     MCGP_SCHED_FENCE();          // one batch at a time: gathers hoisted from later batches cost registers
                     SlotIn in[kStepBatch];
+                    if constexpr (!kLean) {
 #pragma unroll
-                    for (int j = 0; j < kStepBatch; ++j)
-                        if (i0 + j < N) in[j] = load_slot(pk[i0 + j], lut_base);
+                        for (int j = 0; j < kStepBatch; ++j)
+                            if (i0 + j < N) in[j] = load_slot(pk[i0 + j], lut_base);
+                    }
                     uint32_t w[kStepBatch / 4][4], x[kStepBatch / 4][4];
 #pragma unroll
                     for (int b = 0; b < kStepBatch / 4; ++b) {
@@ -1442,19 +1575,30 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                         }
                         MCGP_STAT(15, rare);
                         if (__builtin_expect(!MCGP_ANY(rare), 1)) {
+                            constexpr int R = kLean ? 1 : 2;                  // table rows fetched together (16 registers each)
 #pragma unroll
-                            for (int j0 = 0; j0 < kStepBatch; j0 += 2) {
-                                double zc[2][8];
+                            for (int j0 = 0; j0 < kStepBatch; j0 += R) {
+                                double zc[R][8];
 #pragma unroll
-                                for (int j = 0; j < 2; ++j) norm53_row(zhi[j0 + j], zc[j]);
+                                for (int j = 0; j < R; ++j) norm53_row(zhi[j0 + j], zc[j]);
 #pragma unroll
-                                for (int j = 0; j < 2; ++j)
+                                for (int j = 0; j < R; ++j)
                                     z[j0 + j] = (i0 + j0 + j < N) ? normal53_evaluate(w[(j0 + j) >> 2][(j0 + j) & 3], zc[j], zt[j0 + j]) : 0.0;
                             }
                         } else {
+                            static_assert(!WIDE || kStepBatch == 4, "the out-of-line deviates come four at a time");
+                            const Deviates4 d4 = normal53_batch_from_memory(w[0][0], w[0][1], w[0][2], w[0][3], x[0][0], x[0][1], x[0][2], x[0][3], norm53);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) z[j] = (i0 + j < N) ? d4.z[j] : 0.0;
+                        }
+                        if constexpr (kLean) {
+                            // the deviates are done: only now the slots' gathers
+#pragma unroll
+                            for (int j = 0; j < kStepBatch; ++j) pin(z[j]);
+                            MCGP_SCHED_FENCE();
 #pragma unroll
                             for (int j = 0; j < kStepBatch; ++j)
-                                z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
+                                if (i0 + j < N) in[j] = load_slot(pk[i0 + j], lut_base);
                         }
                     } else {
                         // two table rows are fetched at a time, then evaluated (half the LDS round trips in a row; four at a
@@ -1553,61 +1697,10 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // (ovt_threshold without the ceiling), and a wave with such an attempt (or with more than eight attempts in
                 // a lane) decides the whole pass with the exact 53-bit code below, companion blocks and all.
                 [[maybe_unused]] auto wide_pass_exact = [&]() -> uint32_t {
-                    // Plain code, four attempts at a time: their words in rows 0..3 of the W plane, the companion words
-                    // in rows 4..7.  Returns bit i = the attempt at pair i succeeds.
-                    uint32_t hits53 = 0u;
-                    uint64_t thr64[N];
-                    uint32_t cand = 0u;
-                    {
-                        double pace_prev = 0.0;
+                    PkWords<N> f;
 #pragma unroll
-                        for (int i = 0; i < N; ++i) {
-                            const f64x2 bd = lds_ld_f64x2(G::oDrvB + pk_slot16(pk[i]));
-                            const double pace = bd.x + (double)(pk[i] & k3AgeMask) * bd.y;
-                            thr64[i] = 0ull;
-                            if (i > 0) {
-                                const double dl = (pace_prev - pace) + lds_ld<double>(G::oDrsB + (pk[i] & k3Drs));
-                                const bool c = dl > od31;                                           // :522 (NaN: retired)
-                                double x = ceil_f64(dl * 0x1p21);
-                                x = x < 0x1p52 ? x : 0x1p52;
-                                const uint32_t xh = c ? cvt_u32_f64_sat(x * 0x1p-32) : 0u;
-                                const uint32_t xl = c ? cvt_u32_f64_sat(x - (double)xh * 0x1p32) : 0u;
-                                thr64[i] = ((uint64_t)xh << 32) | (uint64_t)xl;
-                                cand |= c ? (1u << i) : 0u;
-                            }
-                            pace_prev = pace;
-                        }
-                    }
-                    uint32_t rest = cand;
-#pragma unroll 1
-                    for (int chunk = 0; MCGP_ANY(rest != 0u); ++chunk) {
-                        uint32_t m = rest;                                  // `rest` without its 4 lowest set bits
-#pragma unroll 1
-                        for (int k = 0; k < 4 && m != 0u; ++k) m &= m - 1u;
-                        const uint32_t cur = rest & ~m;                     // attempts 4 chunk .. 4 chunk + 3
-                        uint32_t o0, o1, o2, o3;
-                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | (uint32_t)(8 * pass + chunk), k0l, k1l, o0, o1, o2, o3);
-                        lds_st<uint32_t>(w_row(0), o0);
-                        lds_st<uint32_t>(w_row(1), o1);
-                        lds_st<uint32_t>(w_row(2), o2);
-                        lds_st<uint32_t>(w_row(3), o3);
-                        philox4x32_10(c0l, c1l, (uint32_t)lap, kPurposeOvt | kCompanion | (uint32_t)(8 * pass + chunk), k0l, k1l, o0, o1, o2, o3);
-                        lds_st<uint32_t>(w_row(4), o0);
-                        lds_st<uint32_t>(w_row(5), o1);
-                        lds_st<uint32_t>(w_row(6), o2);
-                        lds_st<uint32_t>(w_row(7), o3);
-                        uint32_t h = 0u;
-#pragma unroll
-                        for (int i = 1; i < N; ++i) {
-                            // (a pair outside `cur` reads some other words, or just past the plane: masked out below)
-                            const uint32_t r = (uint32_t)__popc(cur & ((1u << i) - 1u)) * (uint32_t)(B * 4) + tid4;
-                            const uint64_t u = uniform53(lds_ld<uint32_t>(G::oW + r), lds_ld<uint32_t>(G::oW + (uint32_t)(4 * B * 4) + r));
-                            h |= u < thr64[i] ? (1u << i) : 0u;
-                        }
-                        hits53 |= h & cur;
-                        rest = m;
-                    }
-                    return hits53;
+                    for (int i = 0; i < N; ++i) f.v[i] = pk[i];
+                    return wide_pass_exact_fn<N, G>(f, od31, (uint32_t)lap, (uint32_t)pass, c0l, c1l, k0l, k1l, tid);
                 };
                 {
                     // ---- overtakes: draw words ----
@@ -1836,7 +1929,7 @@ race_kernel_reg(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_off
 
 // The reference-width build (mcgp_config.deviates = MCGP_DEVIATES_53): same phases, blocks of 8 waves at 2 waves per SIMD.
 template <int N>
-__global__ void __launch_bounds__((WideGeo<N>::B), MCGP_WIDE_MIN_WAVES)
+__global__ void __launch_bounds__((WideGeo<N>::B), wide_min_waves(N))
 race_kernel_reg_wide(const KParams *__restrict__ P, uint64_t n_sims, uint64_t sim_offset,
                      uint32_t seed_lo, uint32_t seed_hi, unsigned long long *__restrict__ hist,
                      uint8_t *__restrict__ orders, const uint8_t *__restrict__ fixed_grid, uint32_t n_chunks,
@@ -1871,18 +1964,6 @@ struct BatchItem {
 #ifndef MCGP_BATCH_CALL
 #define MCGP_BATCH_CALL 0
 #endif
-// (a function's arguments arrive in vector registers; these are the same in every lane, which readfirstlane says)
-__device__ __forceinline__ uint32_t uniform_u32(uint32_t x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-#else
-    return x;                                   // (the host debugging build: one thread at a time)
-#endif
-}
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t x) { return (uint64_t)uniform_u32((uint32_t)x) | ((uint64_t)uniform_u32((uint32_t)(x >> 32)) << 32); }
-template <typename T>
-__device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
 template <int N>
 #if MCGP_BATCH_CALL
 __device__ __attribute__((noinline))
