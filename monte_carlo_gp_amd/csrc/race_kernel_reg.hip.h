@@ -158,9 +158,8 @@ __host__ __device__ constexpr size_t reg_retire_ws_bytes(int n, size_t lanes) { 
 // The reference-width build at 3 waves per SIMD (168 registers, as the default build at up to 22 cars): its lap step is
 // ordered so that a batch's four deviates are FINISHED before the batch's slots issue their LDS gathers -- the sixteen
 // registers of a table row and the sixty of the gathered values are then never alive together --, table rows are fetched
-// one at a time, and the two rare paths (a table row the block does not hold in LDS; the exact 53-bit overtake pass) are
-// out of line (normal53_batch_from_memory, wide_pass_exact_fn), so that their registers are not the race loop's to pay
-// for.  Same-box A/B against blocks of 8 waves at 2 per SIMD with the default ordering (profiles/r5_ab.txt): 10 cars -18 %,
+// one at a time, a batch whose rows the block does not hold reads them from device memory one deviate at a time, and the
+// exact 53-bit overtake pass is out of line (wide_pass_exact_fn), so that its registers are not the race loop's to pay for.  Same-box A/B against blocks of 8 waves at 2 per SIMD with the default ordering (profiles/r5_ab.txt): 10 cars -18 %,
 // 16 -12 %, 18 -9.5 %, 19 -7 %, 20 -6.5 % (S78 -4 %), 21 +0.4 %, 22 -2.8 %.  MCGP_WIDE_LEAN=0 (diagnostic builds) keeps every
 // field size at 2 waves per SIMD, gathers first, two rows at a time.
 #ifndef MCGP_WIDE_LEAN
@@ -575,6 +574,10 @@ __device__ __forceinline__ uint32_t pit_rule_word(int track, int regime, uint32_
 #ifndef MCGP_DISTINCT_PATH
 #define MCGP_DISTINCT_PATH 1       // update_positions_reg<N, true> for the wave-laps whose fields have no equal times
 #endif
+// Diagnostic (timing only, wrong results in the rare cases): 1 = the two rare paths of the reference-width build are never taken
+#ifndef MCGP_NOCALLS
+#define MCGP_NOCALLS 0
+#endif
 #ifndef MCGP_WIDE_STEP_BATCH
 #define MCGP_WIDE_STEP_BATCH 4
 #endif
@@ -733,25 +736,9 @@ __device__ __forceinline__ uint32_t uniform_u32(uint32_t x)
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x) { return (uint64_t)uniform_u32((uint32_t)x) | ((uint64_t)uniform_u32((uint32_t)(x >> 32)) << 32); }
 template <typename T>
 __device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
-// the rare path of a batch's deviates (a table row the block does not hold in LDS), out of line: all four from the table
-// in device memory
-struct Deviates4 {
-    double z[4];
-};
-__device__ __attribute__((noinline)) inline Deviates4 normal53_batch_from_memory(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
-                                                                               uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
-                                                                               const double *tab_)
-{
-    const double *tab = reinterpret_cast<const double *>(uniform_u64(reinterpret_cast<uint64_t>(tab_)));
-    Deviates4 r;
-    r.z[0] = normal53(w0, x0, tab);
-    r.z[1] = normal53(w1, x1, tab);
-    r.z[2] = normal53(w2, x2, tab);
-    r.z[3] = normal53(w3, x3, tab);
-    return r;
-}
-
-// ... and the exact 53-bit decision of one overtake pass (reg_simulate, overtakes), out of line: the field's pk words go in
+// The exact 53-bit decision of one overtake pass of the reference-width build (reg_simulate, overtakes), OUT OF LINE -- inlined,
+// its forty registers of 64-bit thresholds were the race loop's to pay for; as a call it still costs the loop about 20 scratch
+// accesses per lap (what lives across a call is saved where it is defined: profiles/r5_ab.txt, MCGP_NOCALLS) --: the field's pk words go in
 // by value, everything else it reads is in the block's LDS tables.  Returns bit i = the attempt at pair i succeeds.
 template <int N>
 struct PkWords {
@@ -1574,7 +1561,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                             rare |= (i0 + j < N) && zhi[j] < kRareHi;
                         }
                         MCGP_STAT(15, rare);
-                        if (__builtin_expect(!MCGP_ANY(rare), 1)) {
+                        if (MCGP_NOCALLS || __builtin_expect(!MCGP_ANY(rare), 1)) {
                             constexpr int R = kLean ? 1 : 2;                  // table rows fetched together (16 registers each)
 #pragma unroll
                             for (int j0 = 0; j0 < kStepBatch; j0 += R) {
@@ -1586,10 +1573,15 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                                     z[j0 + j] = (i0 + j0 + j < N) ? normal53_evaluate(w[(j0 + j) >> 2][(j0 + j) & 3], zc[j], zt[j0 + j]) : 0.0;
                             }
                         } else {
-                            static_assert(!WIDE || kStepBatch == 4, "the out-of-line deviates come four at a time");
-                            const Deviates4 d4 = normal53_batch_from_memory(w[0][0], w[0][1], w[0][2], w[0][3], x[0][0], x[0][1], x[0][2], x[0][3], norm53);
+                            // One deviate at a time (the eight coefficients of a row are sixteen registers), in line: as an
+                            // out-of-line call this path cost the race loop 23 scratch accesses per lap -- the register
+                            // allocator saves what lives across a call where it is defined (87.1 -> 85.0 ms).
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) z[j] = (i0 + j < N) ? d4.z[j] : 0.0;
+                            for (int j = 0; j < kStepBatch; ++j) {
+                                z[j] = (i0 + j < N) ? normal53(w[j >> 2][j & 3], x[j >> 2][j & 3], norm53) : 0.0;
+                                pin(z[j]);
+                                MCGP_SCHED_FENCE();
+                            }
                         }
                         if constexpr (kLean) {
                             // the deviates are done: only now the slots' gathers
@@ -1776,7 +1768,7 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
 #pragma unroll
                         for (int i = 1; i < N; ++i) tie |= ((ow[i] ^ thr[i]) >> MCGP_WIDE_TIE_SHIFT) == 0u;
                         MCGP_STAT(11, tie);
-                        if (__builtin_expect(MCGP_ANY(tie || MCGP_WIDE_EXACT || words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
+                        if (!MCGP_NOCALLS && __builtin_expect(MCGP_ANY(tie || MCGP_WIDE_EXACT || words_end > (uint32_t)(kWordRows * B * 4)), 0)) {
                             const uint32_t hits = wide_pass_exact();
 #pragma unroll
                             for (int i = 1; i < N; ++i) {
