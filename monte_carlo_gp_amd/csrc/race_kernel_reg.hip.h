@@ -736,22 +736,16 @@ __device__ __forceinline__ uint32_t uniform_u32(uint32_t x)
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x) { return (uint64_t)uniform_u32((uint32_t)x) | ((uint64_t)uniform_u32((uint32_t)(x >> 32)) << 32); }
 template <typename T>
 __device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
-// The exact 53-bit decision of one overtake pass of the reference-width build (reg_simulate, overtakes), OUT OF LINE -- inlined,
-// its forty registers of 64-bit thresholds were the race loop's to pay for; as a call it still costs the loop about 20 scratch
-// accesses per lap (what lives across a call is saved where it is defined: profiles/r5_ab.txt, MCGP_NOCALLS) --: the field's pk words go in
-// by value, everything else it reads is in the block's LDS tables.  Returns bit i = the attempt at pair i succeeds.
-template <int N>
-struct PkWords {
-    uint32_t v[N];
-};
+// The exact 53-bit decision of one overtake pass of the reference-width build (reg_simulate, overtakes): the path of a draw
+// word that EQUALS the leading word of its threshold, or of a lane with more than eight attempts.  Plain code, four attempts
+// at a time: their words in rows 0..3 of the W plane, the companion words in rows 4..7.  Returns bit i = the attempt at pair i
+// succeeds.  Everything it reads besides the field's pk words is in the block's LDS tables.
 template <int N, class G>
-__device__ __attribute__((noinline)) uint32_t wide_pass_exact_fn(PkWords<N> field, double od31, uint32_t lap, uint32_t pass, uint32_t c0l,
-                                                                 uint32_t c1l, uint32_t k0l_, uint32_t k1l_, uint32_t tid)
+__device__ __forceinline__ uint32_t wide_pass_exact_body(const uint32_t (&pk)[N], double od31, uint32_t lap, uint32_t pass, uint32_t c0l,
+                                                         uint32_t c1l, uint32_t k0l, uint32_t k1l, uint32_t tid)
 {
     constexpr int B = G::B;
     const uint32_t tid4 = tid * 4u;
-    const uint32_t k0l = uniform_u32(k0l_), k1l = uniform_u32(k1l_);          // (the key is the same in every lane)
-    const uint32_t (&pk)[N] = field.v;
     auto w_row_ = [&](int r) -> uint32_t { return G::oW + (uint32_t)r * (B * 4) + tid4; };
     uint32_t hits53 = 0u;
     uint64_t thr64[N];
@@ -806,6 +800,25 @@ __device__ __attribute__((noinline)) uint32_t wide_pass_exact_fn(PkWords<N> fiel
         rest = m;
     }
     return hits53;
+}
+// The same OUT OF LINE, for the builds at 3 waves per SIMD (up to 22 cars): inlined, its forty registers of 64-bit thresholds
+// are the race loop's to pay for -- 880 B of scratch per lane at 168 registers; as a call it costs the loop about 20 scratch
+// accesses per lap (what lives across a call is saved where it is defined: profiles/r5_ab.txt, MCGP_NOCALLS).  The field's
+// pk words go in by value.  The builds at 2 waves per SIMD (23 cars and more, 256 registers) inline the body: a 32-car
+// build with the call gave wrong results in most simulations in three of six otherwise equivalent variants of the
+// surrounding code (a call inside divergent control flow of a kernel that spills 214 scalar registers to vector lanes;
+// tools/dbg_wide_n.py, profiles/r5_ab.txt) -- the call stays where every build of it has been checked at scale
+// (profiles/r5_deep_parity_wide.txt, also with every pass sent through it: MCGP_WIDE_EXACT=1).
+template <int N>
+struct PkWords {
+    uint32_t v[N];
+};
+template <int N, class G>
+__device__ __attribute__((noinline)) uint32_t wide_pass_exact_fn(PkWords<N> field, double od31, uint32_t lap, uint32_t pass, uint32_t c0l,
+                                                                 uint32_t c1l, uint32_t k0l_, uint32_t k1l_, uint32_t tid)
+{
+    // (the key is the same in every lane; a function's arguments arrive in vector registers)
+    return wide_pass_exact_body<N, G>(field.v, od31, lap, pass, c0l, c1l, uniform_u32(k0l_), uniform_u32(k1l_), tid);
 }
 
 // Phase 2: the simulations, one full race per lane.  The unit of work is a WAVE-CHUNK of 64 consecutive simulations,
@@ -1689,10 +1702,14 @@ __device__ __forceinline__ void reg_simulate(const KParams *__restrict__ P, unsi
                 // (ovt_threshold without the ceiling), and a wave with such an attempt (or with more than eight attempts in
                 // a lane) decides the whole pass with the exact 53-bit code below, companion blocks and all.
                 [[maybe_unused]] auto wide_pass_exact = [&]() -> uint32_t {
-                    PkWords<N> f;
+                    if constexpr (kLean) {
+                        PkWords<N> f;
 #pragma unroll
-                    for (int i = 0; i < N; ++i) f.v[i] = pk[i];
-                    return wide_pass_exact_fn<N, G>(f, od31, (uint32_t)lap, (uint32_t)pass, c0l, c1l, k0l, k1l, tid);
+                        for (int i = 0; i < N; ++i) f.v[i] = pk[i];
+                        return wide_pass_exact_fn<N, G>(f, od31, (uint32_t)lap, (uint32_t)pass, c0l, c1l, k0l, k1l, tid);
+                    } else {
+                        return wide_pass_exact_body<N, G>(pk, od31, (uint32_t)lap, (uint32_t)pass, c0l, c1l, k0l, k1l, tid);
+                    }
                 };
                 {
                     // ---- overtakes: draw words ----

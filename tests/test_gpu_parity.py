@@ -533,21 +533,22 @@ def test_reference_width_deviates_match_the_oracle(require_gpu, name):
 
 
 def test_reference_width_deviates_at_every_field_size(require_gpu):
-    """deviates = 53 is built for every field size (19-22-car sessions; the sizes whose blocks hold all /
-    some / none of the binary64 table rows in LDS: RegGeo::kNorm53Rows); a problem only the generic kernel takes is
-    refused with MCGP_E_BAD_ARG, a width other than 32 / 53 with ValueError."""
+    """deviates = 53 is built for every field size, and every one of them is run here (19-22-car sessions, SURVEY section 7;
+    blocks of 12, 11 and 10 waves at 3 waves per SIMD up to 22 cars, 8 and 7 waves at 2 per SIMD beyond; blocks that hold
+    all / some / few of the binary64 table rows in LDS: RegGeo::kNorm53Rows); a problem only the generic kernel takes
+    is refused with MCGP_E_BAD_ARG, a width other than 32 / 53 with ValueError."""
     import copy
     from monte_carlo_gp_amd import RaceConfig, RaceSimulator, _native as N
     case = O.load_case('S60')
-    for n in (1, 2, 7, 18, 19, 22, 25, 28, 29, 32):
+    for n in range(1, 33):
         c = _field(n) if n != 7 else None
         if c is None:
             keep = list(case['grid_probs'])[:7]
             c = dict(case, **{k: {d: (v[:7] if k == 'grid_probs' else v) for d, v in case[k].items() if d in keep}
                               for k in ('grid_probs', 'base_pace', 'tire_deg', 'driver_variance', 'driver_dnf_rates')})
-        ref = O.Problem(c).run(1500, rng=O.RNG_PHILOX53, seed=7, want_orders=True)
+        ref = O.Problem(c).run(1200, rng=O.RNG_PHILOX53, seed=7, want_orders=True)
         sim = RaceSimulator(RaceConfig(**c['config']), set_pop=O.load_cases()['set_pop'], deviates=53)
-        _, orders = sim.run_monte_carlo(1500, c['grid_probs'], c['base_pace'], c['tire_deg'], c['driver_variance'],
+        _, orders = sim.run_monte_carlo(1200, c['grid_probs'], c['base_pace'], c['tire_deg'], c['driver_variance'],
                                         c['driver_dnf_rates'], seed=7, track_condition=c['track_condition'], return_orders=True)
         assert N.lib().mcgp_last_kernel_name(0).decode() == f'mcgp::race_kernel_reg_wide<{n}>'
         assert np.array_equal(orders, ref['orders']) and np.array_equal(sim.last_histogram, ref['hist']), n
