@@ -126,6 +126,21 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     assert abs(d['win_probability_top3']['VER'] - 0.5445) < 0.005
 
 
+def test_bench_without_a_launcher_launches_itself(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher environment: bench.py starts torch.distributed.run as a
+    child process and relays rank 0's line (two ranks sharing GPU 0 over gloo here)."""
+    env = dict(os.environ, MCGP_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
+           '--sims-per-step', '200000', '--no-extras']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert 'starting -m torch.distributed.run' in p.stderr
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['process_group'] == 'gloo' and d['value'] > 0 and len(d['devices']) == 2
+
+
 # ---------------------------------------------------------------------------------------------------------
 # The RCCL branch on the one GPU there is: a world-size-1 `nccl` group (RCCL admits one rank per device), with
 # MCGP_FORCE_PROCESS_GROUP=1 keeping the process group and its collectives although nothing needs reducing.
