@@ -437,7 +437,7 @@ def main():
             'dtype': 'f64',
             'dtype_note': 'race state and every comparison in IEEE binary64 (as the reference); random deviates carry '
                           '32 bits: uniforms w/2^32, normals from a binary32 piecewise-cubic inverse CDF (|err| <= 4.8e-7); '
-                          'measured effect of that substitution on results: profiles/r4_deviate_bias.txt (GPU, 10^9 simulations '
+                          'measured effect of that substitution on results: profiles/r5_deviate_bias.txt (GPU, 10^9 simulations '
                           'against the library\'s own 53-bit mode, which bench.py prices as `deviates53`); stated tolerance of a '
                           'win probability against the reference: 4 SE of a 2x10^7 / 10^8-simulation pair = 0.05 pp at p = 0.5 '
                           '(tests/test_gpu_scale.py)',
@@ -468,7 +468,7 @@ def main():
                                      'Philox block -- computed only where the word alone does not decide (normals always; a '
                                      'Bernoulli draw when the word equals the leading word of its threshold, one in 2^32); '
                                      'binary64 normals from a degree-7 table whose rows sit in LDS; bit-identical to the '
-                                     "oracle's PHILOX53 back-end; effect on results: profiles/r4_deviate_bias.txt (GPU, 10^9 simulations)"}
+                                     "oracle's PHILOX53 back-end; effect on results: profiles/r5_deviate_bias.txt (GPU, 10^9 simulations)"}
         # its own roofline block: the same binding bound, counters of the reference-width kernel
         pcw, why_w = profiled_counters(args.workload + '_wide', per_gpu, bool(os.environ.get('MCGP_LIB')))
         roof53 = {'bound': 'valu-issue', 'achieved': None, 'peak': VALU_PEAK_TINST, 'unit': 'T wave-instructions/s', 'frac': None,
