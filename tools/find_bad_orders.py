@@ -5,7 +5,7 @@ is written to device memory, 20 M at a time, and checked there; the summed histo
     python tools/find_bad_orders.py SEED N_TOTAL WORKLOAD [WORKLOAD ...]     -> gpurun_out/bad_orders.txt (appended)
 
 WORKLOAD: a golden case, N<k> (bench.py's k-car field), FUZZ (every case of tests/golden/fuzz_cases.json) or ALLN
-(N2 .. N32)."""
+(N2 .. N32).  DEVIATES=53 scans the reference-width kernel (configurations it takes)."""
 import ctypes as C
 import json
 import os
@@ -45,8 +45,10 @@ for name in names:
     else:
         case = O.load_case(name)
     drivers = list(case['grid_probs'])
+    if os.environ.get('DEVIATES') == '53' and case['config']['overtake_delta'] < 0:
+        continue
     p = _Problem(RaceConfig(**case['config']), drivers, case['base_pace'], case['tire_deg'], case['driver_variance'],
-                 case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'])
+                 case['driver_dnf_rates'], case['track_condition'], O.load_cases()['set_pop'], int(os.environ.get('DEVIATES', '32')))
     g = RaceSimulator._grid_matrix(case['grid_probs'], drivers)
     n = p.n
     step = min(20_000_000, n_total)
